@@ -1,0 +1,127 @@
+"""Oracle vs every golden artefact the reference holds for this path:
+  Data/r0c1de5e1t_3_5.mn   header quant tables, full parse, byte-exact re-encode
+  Data/SEG_basis.png        the 510 base atoms rendered by writeDictionaryToPNG
+  Data/SEG_KLT_basis.png    base + all 31 622 Y detail rows
+  Data/stats.txt            the variances behind the bit-allocation tables
+(copies under tests/golden/: data files only)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+QY = [8, 1, 1, 3, 3, 5, 9, 8, 14, 13, 12, 21, 19, 17, 16, 28, 25, 23, 20, 18, 33, 30, 27, 24, 22, 39, 35, 32, 29, 26, 24, 42]
+
+
+def test_quant_tables_match_mn_header(oracle, mn_bytes, octx32):
+    """createQuantizationTables(32, 8, 3.5) CompressedImage.cpp:124 == the 96 u16 in the fixture header."""
+    hdr = np.frombuffer(mn_bytes[:14 + 192], np.uint8)
+    assert int.from_bytes(hdr[0:4].tobytes(), "big") == 0x4D4E3234
+    assert int.from_bytes(hdr[4:8].tobytes(), "big") == 4928
+    assert int.from_bytes(hdr[8:12].tobytes(), "big") == 3264
+    assert hdr[12] == 32 and hdr[13] == 8
+    q = np.frombuffer(mn_bytes[14:14 + 192], ">u2").reshape(3, 32)
+    assert q[0].tolist() == QY
+    assert (octx32.quant == q).all()
+
+
+def test_mn_parse_and_byte_exact_reencode(oracle, mn_bytes):
+    """readCompressed :635 consumes the whole file; writeCompressed :403 of the parsed
+    streams reproduces all 3 698 188 bytes -- pins BitBuffer, Golomb, Elias-Fano, RLE,
+    DC diff, Huffman-or-Golomb choice and the MSVC-ordered Huffman tie-breaking."""
+    st = oracle.read_compressed(mn_bytes)
+    assert (st["W"], st["H"], st["K"], st["bs"]) == (4928, 3264, 32, 8)
+    assert len(st["lengths"]) == 753984 == 3 * 616 * 408
+    lens = st["lengths"].reshape(-1, 3)
+    assert lens.max() <= 32
+    # stream i of channel ch holds one symbol per tile whose count exceeds i/2
+    for ch in range(3):
+        for i in range(32):
+            n = int((lens[:, ch] > i).sum())
+            assert len(st["codes"][64 * ch + 2 * i]) == n
+            assert len(st["codes"][64 * ch + 2 * i + 1]) == n
+    # mean atoms kept per tile Y 8.154, U 0.889, V 0.998
+    assert np.allclose(lens.mean(0), [8.154, 0.889, 0.998], atol=2e-3)
+    out = oracle.write_compressed(st)
+    assert len(out) == 3698188
+    assert out == mn_bytes
+
+
+def test_huffman_tie_order_is_load_bearing(oracle, mn_bytes):
+    """With leaves entering the heap in sorted-symbol order instead of MSVC unordered_map
+    order the bytes differ: the emulation is what makes the re-encode exact."""
+    st = oracle.read_compressed(mn_bytes)
+    oracle.lib().mpo_set_umap_order(1)
+    try:
+        out = oracle.write_compressed(st)
+    finally:
+        oracle.lib().mpo_set_umap_order(0)
+    assert out != mn_bytes
+
+
+def _render(D):
+    """writeDictionaryToPNG (Compression.cpp:53-73) + SaveImageGeneric(image<double>) imgloader.cpp:300-327."""
+    rows = D.shape[0]
+    aw = int(np.sqrt(rows))
+    ah = rows // aw + (0 if rows % aw == 0 else 1)
+    pic = np.zeros((ah * 8, aw * 8))
+    for i in range(rows):
+        bx, by = i % aw, i // aw
+        pic[by * 8:(by + 1) * 8, bx * 8:(bx + 1) * 8] = D[i].reshape(8, 8)
+    mn, mx = pic.min(), pic.max()
+    return np.clip(255.0 * ((pic - mn) / (mx - mn)), 0, 255).astype(np.uint8)
+
+
+def test_dictionary_matches_reference_pngs(octx32):
+    """Base atoms and all Y detail rows equal the reference's rendered dictionaries pixel for pixel
+    (ordering, signs, mean removal, normalisation; 8-bit resolution)."""
+    from PIL import Image
+    assert octx32.nbase == 510
+    assert int(octx32.det_off[-1]) == 31622
+    assert set(octx32.det_rows.tolist()) == {62, 63}
+    assert octx32.det_rows[0] == 63 and octx32.det_rows[509] == 63
+    for name, D in (("SEG_basis.png", octx32.base),
+                    ("SEG_KLT_basis.png", np.vstack([octx32.base, octx32.det[0]]))):
+        im = np.array(Image.open(os.path.join(GOLDEN, name)).convert("RGB"))
+        assert (im[:, :, 0] == im[:, :, 1]).all() and (im[:, :, 0] == im[:, :, 2]).all()
+        r = _render(D)
+        assert r.shape == im.shape[:2]
+        assert (r == im[:, :, 0]).all()
+
+
+def test_dictionary_structure(octx32):
+    """atom 0 = +1/8 (DC), atom 509 = -atom 0, unit norms, no NaN."""
+    assert (octx32.base[0] == 0.125).all()
+    assert (octx32.base[509] == -0.125).all()
+    for D in [octx32.base] + octx32.det:
+        assert np.isfinite(D).all()
+        assert np.abs(np.sqrt((D * D).sum(1)) - 1.0).max() < 1e-13
+
+
+def test_variance_constants_match_stats_txt(oracle):
+    """s_varY/U/V (CompressedImage.cpp:17-122) are the 'variance' column of the coeff stats in Data/stats.txt."""
+    L = oracle.lib()
+    L.mpo_variance_constant.restype = __import__("ctypes").c_double
+    txt = open(os.path.join(GOLDEN, "stats.txt")).read()
+    for ch, name in enumerate("YUV"):
+        sec = txt.split(f"{name} coeff stats")[1].split("basisId stats")[0]
+        var = [float(m) for m in re.findall(r"variance ([0-9.eE+-]+)", sec)]
+        assert len(var) == 32
+        for i in range(32):
+            assert L.mpo_variance_constant(ch, i) == pytest.approx(var[i], rel=1e-12)
+
+
+def test_decode_mn_against_jpeg(oracle, mn_bytes):
+    """decodeImage :783 of the fixture vs the committed JPEG of the same photo (reference tree only)."""
+    jpg = "/root/reference/Data/r0c1de5e1t.jpg"
+    if not os.path.exists(jpg):
+        pytest.skip("reference Data/ not present")
+    from PIL import Image
+    img = oracle.decode_image(mn_bytes)
+    ref = np.ascontiguousarray(np.array(Image.open(jpg).convert("RGB")))
+    L = oracle.lib()
+    psnr = L.mpo_psnr(oracle._u8p(ref), oracle._u8p(img), 4928, 3264)
+    # calculatePSNR's formula carries +10*log10(3): 43.84 here == 39.07 dB conventional
+    assert 43.5 < psnr < 44.2
