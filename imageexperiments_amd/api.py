@@ -1,0 +1,215 @@
+"""ctypes binding of libmpcodec.so (include/mpcodec.h) and a thin host-side mirror of the reference's
+`compressed::` / `matching::` interface (CompressionLib/inc/CompressedImage.h, MatchingPursuit.h).
+
+There is no CPU fallback: if the library is missing this module raises, and without a GPU the
+encode entry points raise MpcError(MPC_ERR_NO_DEVICE).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+MAX_K = 32
+HIST_BINS = 8192
+
+MPC_OK, MPC_ERR_ARGUMENT, MPC_ERR_NO_DEVICE, MPC_ERR_HIP, MPC_ERR_BITSTREAM, MPC_ERR_ALLOC = range(6)
+
+
+class MpcError(RuntimeError):
+    def __init__(self, status, text):
+        super().__init__(f"mpcodec status {status}: {text}")
+        self.status = status
+
+
+def library_path():
+    return os.path.join(HERE, "lib", "libmpcodec.so")
+
+
+_lib = None
+
+_u8p = C.POINTER(C.c_uint8)
+_u16p = C.POINTER(C.c_uint16)
+_u32p = C.POINTER(C.c_uint32)
+_dp = C.POINTER(C.c_double)
+_i32p = C.POINTER(C.c_int32)
+
+
+def load_library():
+    """Load libmpcodec.so; raises (loudly) if the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise ImportError(f"{path} is missing: build it with `python -m imageexperiments_amd.build` "
+                          "(there is no CPU fallback for the hot path)")
+    L = C.CDLL(path)
+    vp = C.c_void_p
+    L.mpc_version.restype = C.c_char_p
+    L.mpc_last_error.restype = C.c_char_p
+    L.mpc_context_create.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int, C.POINTER(vp)]
+    L.mpc_context_destroy.argtypes = [vp]
+    for f in ("K", "block_size", "num_base", "detail_rows", "device", "max_waves"):
+        getattr(L, "mpc_context_" + f).argtypes = [vp]
+        getattr(L, "mpc_context_" + f).restype = C.c_int
+    L.mpc_context_get_quant.argtypes = [vp, _dp]
+    L.mpc_context_set_quant.argtypes = [vp, _dp]
+    L.mpc_context_get_dictionary.argtypes = [vp, _dp, _i32p, _dp, _dp, _dp]
+    L.mpc_encode_tiles_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, _dp,
+                                          vp, vp, vp, vp, C.c_int, vp]
+    L.mpc_encode_tiles.argtypes = [vp, _u8p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, _dp,
+                                   _u16p, vp, _dp, _u32p]
+    L.mpc_histogram_device.argtypes = [vp, vp, vp, C.c_longlong, vp, vp]
+    L.mpc_calc_mp.argtypes = [vp, C.c_int, _dp, _dp, vp, C.POINTER(C.c_int)]
+    L.mpc_calc_mp_batch.argtypes = [vp, C.c_int, _dp, _dp, C.c_int, vp, _u16p, _dp, _u32p]
+    _bind_bitstream(L)
+    _lib = L
+    return L
+
+
+def _bind_bitstream(L):
+    """Entry points of the host entropy stage (present once host_bitstream.cpp is part of the build)."""
+    vp = C.c_void_p
+    if not hasattr(L, "mpc_write_compressed"):
+        return
+    L.mpc_free.argtypes = [vp]
+    L.mpc_write_compressed.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _dp, _u16p, C.c_size_t,
+                                       C.POINTER(_u16p), C.POINTER(C.c_size_t), C.POINTER(_u8p), C.POINTER(C.c_size_t)]
+    L.mpc_assemble_streams.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _dp, _u16p, vp,
+                                       C.POINTER(_u8p), C.POINTER(C.c_size_t)]
+    L.mpc_read_compressed.argtypes = [_u8p, C.c_size_t, C.POINTER(vp)]
+    L.mpc_streams_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.mpc_streams_quant.argtypes = [vp, _u16p]
+    L.mpc_streams_length.argtypes = [vp, C.c_int]
+    L.mpc_streams_length.restype = C.c_size_t
+    L.mpc_streams_copy.argtypes = [vp, C.c_int, _u16p]
+    L.mpc_streams_free.argtypes = [vp]
+    L.mpc_huffman_encode.argtypes = [_u16p, C.c_size_t, C.POINTER(_u8p), C.POINTER(C.c_size_t)]
+    L.mpc_huffman_decode.argtypes = [_u8p, C.c_size_t, C.POINTER(_u16p), C.POINTER(C.c_size_t)]
+    L.mpc_rle_encode.argtypes = [_u16p, C.c_size_t, C.POINTER(_u16p), C.POINTER(C.c_size_t)]
+    L.mpc_rle_decode.argtypes = [_u16p, C.c_size_t, C.POINTER(_u16p), C.POINTER(C.c_size_t)]
+    L.mpc_decode_image.argtypes = [vp, _u8p, C.c_size_t, C.POINTER(_u8p), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.mpc_psnr.argtypes = [_u8p, _u8p, C.c_int, C.c_int]
+    L.mpc_psnr.restype = C.c_double
+
+
+def _check(st):
+    if st != MPC_OK:
+        raise MpcError(st, load_library().mpc_last_error().decode())
+
+
+CHOICE_DTYPE = np.dtype([("deltaId", "<u2"), ("intCoeff", "<u2")])
+
+
+class CompressionContext:
+    """compressed::CompressionContext (CompressedImage.h:28-36): K, BlockSize, the dictionary and the three
+    quantisation tables; `device` >= 0 uploads the dictionary once to that GPU."""
+
+    def __init__(self, K=32, block_size=8, bpp=3.5, device=-1):
+        self.L = load_library()
+        h = C.c_void_p()
+        _check(self.L.mpc_context_create(int(K), int(block_size), float(bpp), int(device), C.byref(h)))
+        self.h = h
+        self.K = K
+        self.block_size = block_size
+        self.device = device
+        self.num_base = self.L.mpc_context_num_base(h)
+        self.detail_rows = self.L.mpc_context_detail_rows(h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.mpc_context_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- tables ----------------------------------------------------------------------------------
+    @property
+    def quant(self):
+        q = np.zeros((3, self.K), np.float64)
+        _check(self.L.mpc_context_get_quant(self.h, q.ctypes.data_as(_dp)))
+        return q
+
+    def set_quant(self, q):
+        q = np.ascontiguousarray(q, np.float64).reshape(3, self.K)
+        _check(self.L.mpc_context_set_quant(self.h, q.ctypes.data_as(_dp)))
+
+    def dictionary(self):
+        """-> base[num_base,64], block_rows[num_base], detail[3][detail_rows,64] (host copies)."""
+        n = self.block_size * self.block_size
+        base = np.zeros((self.num_base, n))
+        rows = np.zeros(self.num_base, np.int32)
+        det = [np.zeros((self.detail_rows, n)) for _ in range(3)]
+        _check(self.L.mpc_context_get_dictionary(self.h, base.ctypes.data_as(_dp), rows.ctypes.data_as(_i32p),
+                                                 det[0].ctypes.data_as(_dp), det[1].ctypes.data_as(_dp),
+                                                 det[2].ctypes.data_as(_dp)))
+        return base, rows, det
+
+    @property
+    def max_waves(self):
+        return self.L.mpc_context_max_waves(self.h)
+
+    # -- hot path --------------------------------------------------------------------------------
+    def encode_tiles(self, rgb, tile_row_begin=0, tile_row_end=None, quant=None):
+        """Host-buffer form. rgb: uint8 [H,W,3]. Returns counts[T,3], choices[T,3,K] (structured),
+        energy[T,3], swept[T,3]; tile t = tx*rows + (ty - tile_row_begin)."""
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        H, W = rgb.shape[:2]
+        ty = (H + 7) // 8
+        tx = (W + 7) // 8
+        tile_row_end = ty if tile_row_end is None else tile_row_end
+        T = tx * (tile_row_end - tile_row_begin)
+        counts = np.zeros((T, 3), np.uint16)
+        choices = np.zeros((T, 3, self.K), CHOICE_DTYPE)
+        energy = np.zeros((T, 3), np.float64)
+        swept = np.zeros((T, 3), np.uint32)
+        qp = None
+        if quant is not None:
+            quant = np.ascontiguousarray(quant, np.float64).reshape(3, self.K)
+            qp = quant.ctypes.data_as(_dp)
+        _check(self.L.mpc_encode_tiles(self.h, rgb.ctypes.data_as(_u8p), W, H, 3 * W, tile_row_begin, tile_row_end, qp,
+                                       counts.ctypes.data_as(_u16p), choices.ctypes.data_as(C.c_void_p),
+                                       energy.ctypes.data_as(_dp), swept.ctypes.data_as(_u32p)))
+        return counts, choices, energy, swept
+
+    def encode_tiles_device(self, d_rgb, width, height, row_stride, tile_row_begin, tile_row_end,
+                            d_counts, d_choices, d_energy=0, d_swept=0, quant=None, waves=0, stream=0):
+        """Device-pointer form (ints from tensor.data_ptr()); asynchronous on `stream` (hipStream_t int)."""
+        qp = None
+        if quant is not None:
+            quant = np.ascontiguousarray(quant, np.float64).reshape(3, self.K)
+            qp = quant.ctypes.data_as(_dp)
+        _check(self.L.mpc_encode_tiles_device(self.h, d_rgb, width, height, row_stride, tile_row_begin, tile_row_end,
+                                              qp, d_counts, d_choices, d_energy or None, d_swept or None,
+                                              waves, stream or None))
+
+    def histogram_device(self, d_counts, d_choices, tiles, d_hist, stream=0):
+        _check(self.L.mpc_histogram_device(self.h, d_counts, d_choices, tiles, d_hist, stream or None))
+
+    def calc_mp(self, channel, vectors, quant_k=None):
+        """matching::CalcMPDynamic (MatchingPursuit.h:22) on the device for vectors[n,64].
+        Returns counts[n], choices[n,K], energy[n], swept[n]."""
+        v = np.ascontiguousarray(vectors, np.float64).reshape(-1, 64)
+        n = v.shape[0]
+        counts = np.zeros(n, np.uint16)
+        choices = np.zeros((n, self.K), CHOICE_DTYPE)
+        energy = np.zeros(n)
+        swept = np.zeros(n, np.uint32)
+        qp = None
+        if quant_k is not None:
+            quant_k = np.ascontiguousarray(quant_k, np.float64)
+            qp = quant_k.ctypes.data_as(_dp)
+        _check(self.L.mpc_calc_mp_batch(self.h, channel, qp, v.ctypes.data_as(_dp), n,
+                                        choices.ctypes.data_as(C.c_void_p), counts.ctypes.data_as(_u16p),
+                                        energy.ctypes.data_as(_dp), swept.ctypes.data_as(_u32p)))
+        return counts, choices, energy, swept
+
+
+def create_compression_context(K=32, block_size=8, bpp=3.5, device=-1):
+    """compressed::createCompressionContext(K, blockSize, bppAllocation) (CompressedImage.h:54)."""
+    return CompressionContext(K, block_size, bpp, device)

@@ -1,0 +1,64 @@
+// host_dictionary.h -- product host code (C++), MI355X tile codec.
+//
+// Builds, once per context, everything the device needs for the
+// CompressionLib tile-encode path and lays it out for HBM:
+//   * the segmented line-cut base dictionary      (reference: BasisSet.cpp:204-380)
+//   * the per-segment KLT detail blocks, 3 channels (reference: BasisSet.cpp:513-616,
+//     createBasis :118-152, SymmetricEigenDecomposition symmeigen.cpp:34-244)
+//   * the bit-allocation quantisation tables       (reference: CompressedImage.cpp:124-166)
+// It replaces compressed::createCompressionContext (CompressedImage.cpp:291-315).
+// All arithmetic is IEEE double in the reference's operation order
+// (compiled with -ffp-contract=off) so that the tables are bit-identical to
+// the reference's double path.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+namespace mpc {
+
+constexpr int kMaxK = 32;
+constexpr int kTileN = 64;        // 8x8 tiles: the only block size the device path implements
+constexpr int kBlockPad = 64;     // detail blocks are padded to 64 rows in the transposed layout
+
+struct LineCut { int ax, ay, bx, by; };
+
+struct Dictionary {
+    int block_size = 8;
+    int n = kTileN;                       // pixels per tile
+    int num_base = 0;                     // 510 for 8x8
+    std::vector<LineCut> cuts;            // [num_base]
+    std::vector<double> base;             // [num_base][n]            row-major
+    std::vector<int32_t> block_rows;      // [num_base]   rows of DetailBasis[i] (62 | 63)
+    std::vector<int32_t> block_row_off;   // [num_base+1] prefix sum of block_rows
+    std::vector<double> detail[3];        // [block_row_off.back()][n] row-major, per channel
+    int total_detail_rows() const { return block_row_off.empty() ? 0 : block_row_off.back(); }
+};
+
+// Symmetric eigen-decomposition; vectors returned as columns of `vec` (row-major n*n).
+void symmetric_eigen(const double* a, int n, double* vec, double* val);
+
+// KLT basis of a covariance matrix: rows sorted by (|lambda|, index) descending,
+// first significant entry made positive.
+void klt_basis(const double* cov, int n, double* rows);
+
+double covariance_model(int channel, double dx, double dy);
+
+std::vector<LineCut> distinct_line_cuts(int block_size);
+
+Dictionary build_dictionary(int block_size);
+
+// quant[ch*K + i]
+void quantisation_tables(int K, int block_size, double bpp, double* quant);
+
+// Device-oriented re-layouts -------------------------------------------------
+// base padded to a multiple of `pad_rows` rows with zero rows (a zero row can never be selected:
+// Select starts from bestCoeff = 0 with a strict '>', MatchingPursuit.cpp:9-19).
+std::vector<double> base_padded(const Dictionary& d, int pad_rows, int* padded_rows);
+
+// Transposed detail blocks for the wave-per-tile sweep: for channel ch, block b:
+//   out[((ch*num_base + b) * (n/2) + jj) * 64*2 + row*2 + e] = detail[ch][off[b]+row][2*jj+e]
+// rows >= block_rows[b] are zero. 32 KiB per block.
+std::vector<double> detail_transposed(const Dictionary& d);
+
+}  // namespace mpc

@@ -1,0 +1,359 @@
+// mpcodec_capi.cpp -- product: the C ABI of include/mpcodec.h over the host
+// dictionary builder and the gfx950 kernels.  There is NO CPU fallback for the
+// hot path: without a HIP device mpc_encode_tiles* return MPC_ERR_NO_DEVICE.
+#include "../../include/mpcodec.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <stdexcept>
+#include <vector>
+
+#include "host_dictionary.h"
+#include "mp_device.h"
+
+namespace {
+
+thread_local char g_error[512] = "";
+
+mpc_status fail(mpc_status st, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof g_error, fmt, ap);
+    va_end(ap);
+    return st;
+}
+
+#define HIP_TRY(call)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) return fail(MPC_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+template <class T>
+hipError_t upload(T** dst, const T* src, size_t count) {
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(dst), count * sizeof(T));
+    if (e != hipSuccess) return e;
+    return hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice);
+}
+
+}  // namespace
+
+struct mpc_context {
+    int K = 0, block_size = 0, device = -1;
+    double bpp = 0.0;
+    mpc::Dictionary dict;
+    std::vector<double> quant;        // [3*K]
+    // device residents (uploaded once)
+    double* d_base = nullptr;
+    double* d_detail = nullptr;
+    double* d_detail_t = nullptr;
+    double* d_quant = nullptr;
+    int32_t* d_rows = nullptr;
+    int32_t* d_rowoff = nullptr;
+    unsigned* d_queue = nullptr;
+    int base_rows_padded = 0;
+    int max_waves = 0;
+};
+
+extern "C" {
+
+const char* mpc_version(void) { return "mpcodec 0.1 (gfx950)"; }
+const char* mpc_last_error(void) { return g_error; }
+
+mpc_status mpc_context_create(int K, int block_size, double bpp, int device, mpc_context** out) {
+    if (!out) return fail(MPC_ERR_ARGUMENT, "out is null");
+    *out = nullptr;
+    if (K < 1 || K > MPC_MAX_K) return fail(MPC_ERR_ARGUMENT, "K=%d out of range 1..%d", K, MPC_MAX_K);
+    if (block_size < 1 || block_size > 8) return fail(MPC_ERR_ARGUMENT, "block size %d out of range 1..8", block_size);
+    if (device >= 0 && block_size != 8)
+        return fail(MPC_ERR_ARGUMENT, "the device path implements 8x8 tiles only (got %d)", block_size);
+    mpc_context* c = new (std::nothrow) mpc_context;
+    if (!c) return fail(MPC_ERR_ALLOC, "out of memory");
+    try {
+        c->K = K;
+        c->block_size = block_size;
+        c->bpp = bpp;
+        c->dict = mpc::build_dictionary(block_size);
+        c->quant.resize(3 * static_cast<size_t>(K));
+        mpc::quantisation_tables(K, block_size, bpp, c->quant.data());
+    } catch (const std::exception& e) {
+        delete c;
+        return fail(MPC_ERR_ARGUMENT, "%s", e.what());
+    }
+    c->device = device;
+    if (device >= 0) {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device) {
+            delete c;
+            return fail(MPC_ERR_NO_DEVICE, "HIP device %d not available (%d devices visible)", device, ndev);
+        }
+        hipError_t e = hipSetDevice(device);
+        std::vector<double> base = mpc::base_padded(c->dict, 2, &c->base_rows_padded);
+        std::vector<double> det_t = mpc::detail_transposed(c->dict);
+        const size_t det_rows = static_cast<size_t>(c->dict.total_detail_rows());
+        std::vector<double> det(3 * det_rows * mpc::kTileN);
+        for (int ch = 0; ch < 3; ++ch)
+            std::memcpy(det.data() + ch * det_rows * mpc::kTileN, c->dict.detail[ch].data(),
+                        det_rows * mpc::kTileN * sizeof(double));
+        if (e == hipSuccess) e = upload(&c->d_base, base.data(), base.size());
+        if (e == hipSuccess) e = upload(&c->d_detail, det.data(), det.size());
+        if (e == hipSuccess) e = upload(&c->d_detail_t, det_t.data(), det_t.size());
+        if (e == hipSuccess) e = upload(&c->d_quant, c->quant.data(), c->quant.size());
+        if (e == hipSuccess) e = upload(&c->d_rows, c->dict.block_rows.data(), c->dict.block_rows.size());
+        if (e == hipSuccess) e = upload(&c->d_rowoff, c->dict.block_row_off.data(), c->dict.block_row_off.size());
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_queue), 64 * sizeof(unsigned));
+        if (e != hipSuccess) {
+            mpc_context_destroy(c);
+            return fail(MPC_ERR_HIP, "device setup failed: %s", hipGetErrorString(e));
+        }
+        c->max_waves = mpc::encode_max_resident_waves();
+    }
+    *out = c;
+    return MPC_OK;
+}
+
+void mpc_context_destroy(mpc_context* c) {
+    if (!c) return;
+    if (c->device >= 0) {
+        (void)hipSetDevice(c->device);
+        (void)hipFree(c->d_base);
+        (void)hipFree(c->d_detail);
+        (void)hipFree(c->d_detail_t);
+        (void)hipFree(c->d_quant);
+        (void)hipFree(c->d_rows);
+        (void)hipFree(c->d_rowoff);
+        (void)hipFree(c->d_queue);
+    }
+    delete c;
+}
+
+int mpc_context_K(const mpc_context* c) { return c ? c->K : 0; }
+int mpc_context_block_size(const mpc_context* c) { return c ? c->block_size : 0; }
+int mpc_context_num_base(const mpc_context* c) { return c ? c->dict.num_base : 0; }
+int mpc_context_detail_rows(const mpc_context* c) { return c ? c->dict.total_detail_rows() : 0; }
+int mpc_context_device(const mpc_context* c) { return c ? c->device : -1; }
+int mpc_context_max_waves(const mpc_context* c) { return c ? c->max_waves : 0; }
+
+mpc_status mpc_context_get_quant(const mpc_context* c, double* quant) {
+    if (!c || !quant) return fail(MPC_ERR_ARGUMENT, "null argument");
+    std::memcpy(quant, c->quant.data(), c->quant.size() * sizeof(double));
+    return MPC_OK;
+}
+
+mpc_status mpc_context_set_quant(mpc_context* c, const double* quant) {
+    if (!c || !quant) return fail(MPC_ERR_ARGUMENT, "null argument");
+    std::memcpy(c->quant.data(), quant, c->quant.size() * sizeof(double));
+    if (c->device >= 0) {
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipMemcpy(c->d_quant, quant, c->quant.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    return MPC_OK;
+}
+
+mpc_status mpc_context_get_dictionary(const mpc_context* c, double* base, int32_t* block_rows, double* dy, double* du,
+                                      double* dv) {
+    if (!c) return fail(MPC_ERR_ARGUMENT, "null context");
+    if (base) std::memcpy(base, c->dict.base.data(), c->dict.base.size() * sizeof(double));
+    if (block_rows) std::memcpy(block_rows, c->dict.block_rows.data(), c->dict.block_rows.size() * sizeof(int32_t));
+    double* det[3] = {dy, du, dv};
+    for (int ch = 0; ch < 3; ++ch)
+        if (det[ch]) std::memcpy(det[ch], c->dict.detail[ch].data(), c->dict.detail[ch].size() * sizeof(double));
+    return MPC_OK;
+}
+
+static int pick_waves(const mpc_context* c, long long tasks, int requested) {
+    if (requested > 0) return requested;
+    long long need = (tasks + 63) / 64;
+    long long w = c->max_waves > 0 ? c->max_waves : 1024;
+    if (need < w) w = need;
+    return static_cast<int>(w < 1 ? 1 : w);
+}
+
+mpc_status mpc_encode_tiles_device(mpc_context* c, const uint8_t* d_rgb, int width, int height, size_t row_stride,
+                                   int tile_row_begin, int tile_row_end, const double* quant, uint16_t* d_counts,
+                                   mpc_basis_choice* d_choices, double* d_energy, uint32_t* d_swept, int waves,
+                                   void* stream) {
+    if (!c) return fail(MPC_ERR_ARGUMENT, "null context");
+    if (c->device < 0) return fail(MPC_ERR_NO_DEVICE, "context was created without a device; there is no CPU fallback");
+    if (!d_rgb || !d_counts || !d_choices) return fail(MPC_ERR_ARGUMENT, "null buffer");
+    if (width < 1 || height < 1 || row_stride < static_cast<size_t>(3) * width)
+        return fail(MPC_ERR_ARGUMENT, "bad geometry %dx%d stride %zu", width, height, row_stride);
+    const int tiles_x = (width + 7) / 8, tiles_y = (height + 7) / 8;
+    if (tile_row_begin < 0 || tile_row_end > tiles_y || tile_row_begin >= tile_row_end)
+        return fail(MPC_ERR_ARGUMENT, "tile rows [%d,%d) outside 0..%d", tile_row_begin, tile_row_end, tiles_y);
+    const long long tiles = static_cast<long long>(tiles_x) * (tile_row_end - tile_row_begin);
+    if (tiles * 3 >= (1LL << 31)) return fail(MPC_ERR_ARGUMENT, "stripe too large");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (quant) HIP_TRY(hipMemcpyAsync(c->d_quant, quant, 3 * sizeof(double) * c->K, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(c->d_queue, 0, sizeof(unsigned), s));
+    HIP_TRY(hipMemsetAsync(d_choices, 0, sizeof(mpc_basis_choice) * tiles * 3 * c->K, s));
+    mpc::EncodeParams p{};
+    p.rgb = d_rgb;
+    p.width = width;
+    p.height = height;
+    p.row_stride = static_cast<long long>(row_stride);
+    p.tile_row_begin = tile_row_begin;
+    p.tile_rows = tile_row_end - tile_row_begin;
+    p.tiles_x = tiles_x;
+    p.K = c->K;
+    p.base = c->d_base;
+    p.num_base = c->dict.num_base;
+    p.base_rows_padded = c->base_rows_padded;
+    p.detail = c->d_detail;
+    p.detail_t = c->d_detail_t;
+    p.detail_rows = c->dict.total_detail_rows();
+    p.block_rows = c->d_rows;
+    p.block_row_off = c->d_rowoff;
+    p.quant = c->d_quant;
+    p.counts = d_counts;
+    p.choices = reinterpret_cast<uint32_t*>(d_choices);
+    p.energy = d_energy;
+    p.swept = d_swept;
+    p.queue = c->d_queue;
+    p.vec_in = nullptr;
+    const int err = mpc::launch_encode(p, pick_waves(c, tiles * 3, waves), stream);
+    if (err != 0) return fail(MPC_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(err)));
+    return MPC_OK;
+}
+
+mpc_status mpc_encode_tiles(mpc_context* c, const uint8_t* rgb, int width, int height, size_t row_stride,
+                            int tile_row_begin, int tile_row_end, const double* quant, uint16_t* counts,
+                            mpc_basis_choice* choices, double* energy, uint32_t* swept) {
+    if (!c) return fail(MPC_ERR_ARGUMENT, "null context");
+    if (c->device < 0) return fail(MPC_ERR_NO_DEVICE, "context was created without a device; there is no CPU fallback");
+    if (!rgb || !counts || !choices) return fail(MPC_ERR_ARGUMENT, "null buffer");
+    HIP_TRY(hipSetDevice(c->device));
+    const int tiles_x = (width + 7) / 8;
+    const long long tiles = static_cast<long long>(tiles_x) * (tile_row_end - tile_row_begin);
+    if (tiles <= 0) return fail(MPC_ERR_ARGUMENT, "empty stripe");
+    uint8_t* d_rgb = nullptr;
+    uint16_t* d_counts = nullptr;
+    mpc_basis_choice* d_choices = nullptr;
+    double* d_energy = nullptr;
+    uint32_t* d_swept = nullptr;
+    const size_t img_bytes = row_stride * static_cast<size_t>(height);
+    mpc_status st = MPC_OK;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_rgb), img_bytes);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_counts), sizeof(uint16_t) * tiles * 3);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_choices), sizeof(mpc_basis_choice) * tiles * 3 * c->K);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_energy), sizeof(double) * tiles * 3);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_swept), sizeof(uint32_t) * tiles * 3);
+    if (e == hipSuccess) e = hipMemcpy(d_rgb, rgb, img_bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        st = mpc_encode_tiles_device(c, d_rgb, width, height, row_stride, tile_row_begin, tile_row_end, quant, d_counts,
+                                     d_choices, d_energy, d_swept, 0, nullptr);
+        if (st == MPC_OK) {
+            e = hipDeviceSynchronize();
+            if (e == hipSuccess) e = hipMemcpy(counts, d_counts, sizeof(uint16_t) * tiles * 3, hipMemcpyDeviceToHost);
+            if (e == hipSuccess)
+                e = hipMemcpy(choices, d_choices, sizeof(mpc_basis_choice) * tiles * 3 * c->K, hipMemcpyDeviceToHost);
+            if (e == hipSuccess && energy) e = hipMemcpy(energy, d_energy, sizeof(double) * tiles * 3, hipMemcpyDeviceToHost);
+            if (e == hipSuccess && swept) e = hipMemcpy(swept, d_swept, sizeof(uint32_t) * tiles * 3, hipMemcpyDeviceToHost);
+        }
+    }
+    (void)hipFree(d_rgb);
+    (void)hipFree(d_counts);
+    (void)hipFree(d_choices);
+    (void)hipFree(d_energy);
+    (void)hipFree(d_swept);
+    if (st != MPC_OK) return st;
+    if (e != hipSuccess) return fail(MPC_ERR_HIP, "HIP failure: %s", hipGetErrorString(e));
+    return MPC_OK;
+}
+
+mpc_status mpc_histogram_device(mpc_context* c, const uint16_t* d_counts, const mpc_basis_choice* d_choices,
+                                long long tiles, uint32_t* d_hist, void* stream) {
+    if (!c) return fail(MPC_ERR_ARGUMENT, "null context");
+    if (c->device < 0) return fail(MPC_ERR_NO_DEVICE, "context was created without a device");
+    if (!d_counts || !d_choices || !d_hist || tiles < 1) return fail(MPC_ERR_ARGUMENT, "bad argument");
+    mpc::HistParams h{};
+    h.counts = d_counts;
+    h.choices = reinterpret_cast<const uint32_t*>(d_choices);
+    h.tiles = tiles;
+    h.K = c->K;
+    h.hist = d_hist;
+    const int err = mpc::launch_histogram(h, stream);
+    if (err != 0) return fail(MPC_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(err)));
+    return MPC_OK;
+}
+
+mpc_status mpc_calc_mp_batch(mpc_context* c, int channel, const double* quant_k, const double* inputs, int count,
+                             mpc_basis_choice* choices, uint16_t* counts, double* energy, uint32_t* swept) {
+    if (!c) return fail(MPC_ERR_ARGUMENT, "null context");
+    if (c->device < 0) return fail(MPC_ERR_NO_DEVICE, "context was created without a device; there is no CPU fallback");
+    if (channel < 0 || channel > 2 || !inputs || !choices || !counts || count < 1)
+        return fail(MPC_ERR_ARGUMENT, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    const int K = c->K;
+    double* d_in = nullptr;
+    uint16_t* d_counts = nullptr;
+    uint32_t* d_choices = nullptr;
+    double* d_energy = nullptr;
+    uint32_t* d_swept = nullptr;
+    double* d_q = nullptr;
+    std::vector<double> q(c->quant);
+    if (quant_k) std::memcpy(q.data() + static_cast<size_t>(channel) * K, quant_k, sizeof(double) * K);
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_in), sizeof(double) * 64 * count);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_counts), sizeof(uint16_t) * count);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_choices), sizeof(uint32_t) * count * K);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_energy), sizeof(double) * count);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_swept), sizeof(uint32_t) * count);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_q), sizeof(double) * 3 * K);
+    if (e == hipSuccess) e = hipMemcpy(d_in, inputs, sizeof(double) * 64 * count, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_q, q.data(), sizeof(double) * 3 * K, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(d_choices, 0, sizeof(uint32_t) * count * K);
+    if (e == hipSuccess) e = hipMemset(c->d_queue, 0, sizeof(unsigned));
+    int err = 0;
+    if (e == hipSuccess) {
+        mpc::EncodeParams p{};
+        p.K = K;
+        p.base = c->d_base;
+        p.num_base = c->dict.num_base;
+        p.base_rows_padded = c->base_rows_padded;
+        p.detail = c->d_detail;
+        p.detail_t = c->d_detail_t;
+        p.detail_rows = c->dict.total_detail_rows();
+        p.block_rows = c->d_rows;
+        p.block_row_off = c->d_rowoff;
+        p.quant = d_q;
+        p.counts = d_counts;
+        p.choices = d_choices;
+        p.energy = d_energy;
+        p.swept = d_swept;
+        p.queue = c->d_queue;
+        p.vec_in = d_in;
+        p.vec_count = count;
+        p.vec_channel = channel;
+        err = mpc::launch_encode(p, pick_waves(c, count, 0), nullptr);
+        if (err == 0) e = hipDeviceSynchronize();
+        if (err == 0 && e == hipSuccess) e = hipMemcpy(counts, d_counts, sizeof(uint16_t) * count, hipMemcpyDeviceToHost);
+        if (err == 0 && e == hipSuccess)
+            e = hipMemcpy(choices, d_choices, sizeof(uint32_t) * count * K, hipMemcpyDeviceToHost);
+        if (err == 0 && e == hipSuccess && energy) e = hipMemcpy(energy, d_energy, sizeof(double) * count, hipMemcpyDeviceToHost);
+        if (err == 0 && e == hipSuccess && swept) e = hipMemcpy(swept, d_swept, sizeof(uint32_t) * count, hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(d_in);
+    (void)hipFree(d_counts);
+    (void)hipFree(d_choices);
+    (void)hipFree(d_energy);
+    (void)hipFree(d_swept);
+    (void)hipFree(d_q);
+    if (err != 0) return fail(MPC_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(err)));
+    if (e != hipSuccess) return fail(MPC_ERR_HIP, "HIP failure: %s", hipGetErrorString(e));
+    return MPC_OK;
+}
+
+mpc_status mpc_calc_mp(mpc_context* c, int channel, const double* quant_k, const double* input64,
+                       mpc_basis_choice* choices, int* count) {
+    if (!count) return fail(MPC_ERR_ARGUMENT, "null count");
+    uint16_t n = 0;
+    mpc_status st = mpc_calc_mp_batch(c, channel, quant_k, input64, 1, choices, &n, nullptr, nullptr);
+    if (st == MPC_OK) *count = n;
+    return st;
+}
+
+}  // extern "C"

@@ -1,0 +1,129 @@
+/*
+ * mpcodec.h -- C ABI of libmpcodec.so: the MI355X (gfx950) drop-in for the
+ * CompressionLib per-tile encode path of mnesbit/ImageExperiments.
+ *
+ * Plain pointers and sizes only; no exceptions cross this boundary (the
+ * reference throws heap-allocated std::range_error*; here every entry point
+ * returns an mpc_status and mpc_last_error() carries the text).
+ * Citations are relative to the reference tree (/root/reference).
+ *
+ * Reference interface each entry point replaces:
+ *   mpc_context_create        compressed::createCompressionContext        CompressionLib/inc/CompressedImage.h:54
+ *                             (createQuantizationTables CompressedImage.cpp:124, distinctLineShapes BasisSet.cpp:204,
+ *                              createSegmentDictionary :299, createIntraSegmentDictionary :513)
+ *   mpc_context_get/set_quant CompressionContext::{Y,U,V}.Quant           CompressedImage.h:22-36 (Compression.cpp:104-110
+ *                                                                          overwrites them for "max" quality)
+ *   mpc_encode_tiles_device   the tile loop of compressed::encodeImage    CompressedImage.cpp:535-573, i.e. per tile
+ *   mpc_encode_tiles          and channel: gather + img::YUVFromRGB (misc.cpp:7) + matching::CalcMPDynamic
+ *                             (MatchingPursuit.h:22, MatchingPursuit.cpp:39) over compressed::dynamicBasis
+ *                             (CompressedImage.cpp:212)
+ *   mpc_histogram_device      (new) per-stream symbol counts feeding huffman::huffmanEncode / golombCodeLength
+ *                             (CompressedImage.cpp:359-379); the multi-GPU all-reduce operand
+ *   mpc_calc_mp               matching::CalcMPDynamic on one vector       MatchingPursuit.h:22 (Compression.cpp:250 "-s" mode)
+ *   mpc_write_compressed      compressed::writeCompressed (static)        CompressedImage.cpp:403
+ *   mpc_read_compressed       compressed::readCompressed                  CompressedImage.cpp:635
+ *   mpc_encode_image          compressed::encodeImage                     CompressedImage.h:59
+ *   mpc_decode_image          compressed::decodeImage                     CompressedImage.h:75
+ *   mpc_psnr                  compressed::calculatePSNR                   CompressedImage.h:57
+ *   mpc_huffman_encode/decode huffman::huffmanEncode / huffmanDecode      Huffman.h:15-19
+ *   mpc_rle_encode/decode     huffman::runLengthEncode / runLengthDecode  Huffman.h:12-13
+ */
+#ifndef MPCODEC_H
+#define MPCODEC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPC_MAX_K 32
+#define MPC_HIST_BINS 8192
+
+typedef enum {
+    MPC_OK = 0,
+    MPC_ERR_ARGUMENT = 1,      /* bad K / block size / null pointer / geometry            */
+    MPC_ERR_NO_DEVICE = 2,     /* context has no GPU (created with device < 0) or HIP failed to initialise */
+    MPC_ERR_HIP = 3,           /* a HIP runtime call failed; see mpc_last_error            */
+    MPC_ERR_BITSTREAM = 4,     /* "Invalid input data" / "Invalid bitstream" of the reference */
+    MPC_ERR_ALLOC = 5
+} mpc_status;
+
+/* matching::BasisChoice, MatchingPursuit.h:13-17 (same layout: two u16) */
+typedef struct {
+    uint16_t deltaId;
+    uint16_t intCoeff;
+} mpc_basis_choice;
+
+typedef struct mpc_context mpc_context;
+
+const char* mpc_version(void);
+/* text of the last failure on this thread (never NULL) */
+const char* mpc_last_error(void);
+
+/* K in 1..32, block_size must be 8 for the device path (host-only contexts accept 1..8).
+ * device >= 0: HIP device ordinal, dictionary uploaded once; device < 0: host-only context
+ * (dictionary/quant queries and the bitstream entry points work, encode_tiles does not). */
+mpc_status mpc_context_create(int K, int block_size, double bpp_allocation, int device, mpc_context** out);
+void mpc_context_destroy(mpc_context* ctx);
+
+int mpc_context_K(const mpc_context* ctx);
+int mpc_context_block_size(const mpc_context* ctx);
+int mpc_context_num_base(const mpc_context* ctx);          /* 510 for 8x8 */
+int mpc_context_detail_rows(const mpc_context* ctx);       /* 31622 for 8x8, per channel */
+int mpc_context_device(const mpc_context* ctx);
+int mpc_context_max_waves(const mpc_context* ctx);          /* resident waves of the encode kernel on the device */
+
+/* quant[3*K]: Y then U then V */
+mpc_status mpc_context_get_quant(const mpc_context* ctx, double* quant);
+mpc_status mpc_context_set_quant(mpc_context* ctx, const double* quant);
+
+/* Copies of the host dictionary (any pointer may be NULL):
+ * base[num_base*64], block_rows[num_base], detail_{y,u,v}[detail_rows*64] */
+mpc_status mpc_context_get_dictionary(const mpc_context* ctx, double* base, int32_t* block_rows,
+                                      double* detail_y, double* detail_u, double* detail_v);
+
+/* ---- the hot path -------------------------------------------------------------------------------------
+ * Encodes the tile rows [tile_row_begin, tile_row_end) of one RGB frame resident in device memory.
+ * d_rgb: row-major, 3 bytes per pixel, `row_stride` bytes between rows (img::image<rgb>, image.h:123-131).
+ * Tiles outside the image are zero filled (CompressedImage.cpp:548-552).
+ * Outputs (device memory, caller allocated), tile index t = tx * rows + (ty - tile_row_begin), rows =
+ * tile_row_end - tile_row_begin, i.e. the reference's x-outer / y-inner order within the stripe:
+ *   d_counts [tiles][3]      u16   CalcMPDynamic's return value per channel (Y,U,V)
+ *   d_choices[tiles][3][K]         records 0..count (the terminating record is written as the reference
+ *                                   writes it, MatchingPursuit.cpp:50-69); entries beyond are zero
+ *   d_energy [tiles][3]      f64   sum of squares of the final residual (diagnostic, not in CompressionLib)
+ *   d_swept  [tiles][3]      u32   dictionary rows correlated, SURVEY 8(d) "S"
+ * d_energy / d_swept may be NULL.  quant: host pointer to 3*K doubles or NULL for the context's tables.
+ * stream: hipStream_t (NULL = default stream).  Asynchronous; no allocation, no synchronisation.
+ * waves: grid size in wave64 workgroups, 0 = automatic. */
+mpc_status mpc_encode_tiles_device(mpc_context* ctx, const uint8_t* d_rgb, int width, int height, size_t row_stride,
+                                   int tile_row_begin, int tile_row_end, const double* quant,
+                                   uint16_t* d_counts, mpc_basis_choice* d_choices, double* d_energy, uint32_t* d_swept,
+                                   int waves, void* stream);
+
+/* Same with host buffers: uploads the frame, runs the kernel, copies the records back, synchronises. */
+mpc_status mpc_encode_tiles(mpc_context* ctx, const uint8_t* rgb, int width, int height, size_t row_stride,
+                            int tile_row_begin, int tile_row_end, const double* quant,
+                            uint16_t* counts, mpc_basis_choice* choices, double* energy, uint32_t* swept);
+
+/* d_hist[(1 + 6K)][MPC_HIST_BINS] u32 += symbol counts of the records of `tiles` tiles:
+ * row 0 = lengths, row 1 + 2K*ch + 2i = deltaId at step i, +1 = intCoeff at step i. Asynchronous. */
+mpc_status mpc_histogram_device(mpc_context* ctx, const uint16_t* d_counts, const mpc_basis_choice* d_choices,
+                                long long tiles, uint32_t* d_hist, void* stream);
+
+/* matching::CalcMPDynamic on one 64-vector on the device (Compression.cpp -s mode); channel 0/1/2.
+ * choices[K]; *count receives the return value. Synchronous. */
+mpc_status mpc_calc_mp(mpc_context* ctx, int channel, const double* quant_k, const double* input64,
+                       mpc_basis_choice* choices, int* count);
+
+/* Batch form: `count` vectors inputs[count][64] of one channel; counts[count], choices[count][K];
+ * energy[count] / swept[count] optional. quant_k: K steps for that channel or NULL = context table. */
+mpc_status mpc_calc_mp_batch(mpc_context* ctx, int channel, const double* quant_k, const double* inputs, int count,
+                             mpc_basis_choice* choices, uint16_t* counts, double* energy, uint32_t* swept);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPCODEC_H */
