@@ -40,6 +40,10 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 (soname libamdhip64.so.7). Loading
+    # torch FIRST makes the dynamic linker bind libmpcodec.so's libamdhip64.so.7 dependency to that same copy;
+    # the other order leaves two runtimes in the process and the second one sees no devices.
+    import torch  # noqa: F401
     path = library_path()
     if not os.path.exists(path):
         raise ImportError(f"{path} is missing: build it with `python -m imageexperiments_amd.build` "
@@ -57,6 +61,8 @@ def load_library():
     L.mpc_context_set_quant.argtypes = [vp, _dp]
     L.mpc_context_get_dictionary.argtypes = [vp, _dp, _i32p, _dp, _dp, _dp]
     L.mpc_encode_tiles_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, _dp,
+                                          vp, vp, vp, vp, C.c_int, vp]
+    L.mpc_encode_batch_device.argtypes = [vp, vp, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, _dp,
                                           vp, vp, vp, vp, C.c_int, vp]
     L.mpc_encode_tiles.argtypes = [vp, _u8p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, _dp,
                                    _u16p, vp, _dp, _u32p]
@@ -187,6 +193,17 @@ class CompressionContext:
         _check(self.L.mpc_encode_tiles_device(self.h, d_rgb, width, height, row_stride, tile_row_begin, tile_row_end,
                                               qp, d_counts, d_choices, d_energy or None, d_swept or None,
                                               waves, stream or None))
+
+    def encode_batch_device(self, d_rgb, frames, frame_stride, width, height, row_stride, tile_row_begin, tile_row_end,
+                            d_counts, d_choices, d_energy=0, d_swept=0, quant=None, waves=0, stream=0):
+        """`frames` frames `frame_stride` bytes apart, same tile rows of each, one launch."""
+        qp = None
+        if quant is not None:
+            quant = np.ascontiguousarray(quant, np.float64).reshape(3, self.K)
+            qp = quant.ctypes.data_as(_dp)
+        _check(self.L.mpc_encode_batch_device(self.h, d_rgb, frames, frame_stride, width, height, row_stride,
+                                              tile_row_begin, tile_row_end, qp, d_counts, d_choices,
+                                              d_energy or None, d_swept or None, waves, stream or None))
 
     def histogram_device(self, d_counts, d_choices, tiles, d_hist, stream=0):
         _check(self.L.mpc_histogram_device(self.h, d_counts, d_choices, tiles, d_hist, stream or None))

@@ -12,6 +12,8 @@ struct EncodeParams {
     const uint8_t* rgb;
     int width, height;
     long long row_stride;            // bytes between image rows
+    int frames;                      // batch of equally sized frames, `frame_stride` bytes apart
+    long long frame_stride;
     // stripe of tile rows handled by this launch
     int tile_row_begin, tile_rows;   // rows [begin, begin+tile_rows)
     int tiles_x;
@@ -26,7 +28,7 @@ struct EncodeParams {
     const int32_t* block_rows;       // [num_base]
     const int32_t* block_row_off;    // [num_base+1]
     const double* quant;             // [3][K] (device memory)
-    // outputs (device memory); tile index t = tx*tile_rows + (ty - tile_row_begin)
+    // outputs (device memory); tile index t = frame*tiles + tx*tile_rows + (ty - tile_row_begin)
     uint16_t* counts;                // [tiles][3]
     uint32_t* choices;               // [tiles][3][K]  lo16 = deltaId, hi16 = intCoeff (BasisChoice layout)
     double* energy;                  // [tiles][3]  sum of squared residual at termination

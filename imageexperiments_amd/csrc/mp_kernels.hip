@@ -62,7 +62,8 @@ __global__ __launch_bounds__(64, 2) void mp_encode_kernel(const EncodeParams p)
     const int K = p.K;
     const bool vector_mode = p.vec_in != nullptr;
     const int ntiles = p.tiles_x * p.tile_rows;
-    const int ntasks = vector_mode ? p.vec_count : 3 * ntiles;
+    const int nunits = ntiles * p.frames;                 // tiles of the whole batch
+    const int ntasks = vector_mode ? p.vec_count : 3 * nunits;
     const scalar_f64_ptr base_s = (scalar_f64_ptr)(uintptr_t)p.base;
     const scalar_i32_ptr rows_s = (scalar_i32_ptr)(uintptr_t)p.block_rows;
     const scalar_i32_ptr rowoff_s = (scalar_i32_ptr)(uintptr_t)p.block_row_off;
@@ -105,17 +106,20 @@ __global__ __launch_bounds__(64, 2) void mp_encode_kernel(const EncodeParams p)
                                 if ((j & 15) == 15) __builtin_amdgcn_sched_barrier(0);
                             }
                         } else {
-                        ch = ticket / ntiles;                    // all Y first, then U, then V
-                        const int tile = ticket - ch * ntiles;
+                        ch = ticket / nunits;                    // all Y first, then U, then V
+                        const int unit = ticket - ch * nunits;
+                        const int frame = unit / ntiles;
+                        const int tile = unit - frame * ntiles;
                         const int tx = tile / p.tile_rows;
                         const int ty = p.tile_row_begin + (tile - tx * p.tile_rows);
-                        out_index = tile * 3 + ch;
+                        out_index = unit * 3 + ch;
+                        const uint8_t* frame_rgb = p.rgb + (long long)frame * p.frame_stride;
                         const int x0 = tx * 8, y0 = ty * 8;
 #pragma unroll
                         for (int dy = 0; dy < 8; ++dy) {
                             const int v = y0 + dy;
                             const int vc = v < p.height ? v : p.height - 1;      // clamped address, value masked below
-                            const uint8_t* line = p.rgb + (long long)vc * p.row_stride;
+                            const uint8_t* line = frame_rgb + (long long)vc * p.row_stride;
 #pragma unroll
                             for (int dx = 0; dx < 8; ++dx) {
                                 const int u = x0 + dx;

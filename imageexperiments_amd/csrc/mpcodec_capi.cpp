@@ -173,10 +173,10 @@ static int pick_waves(const mpc_context* c, long long tasks, int requested) {
     return static_cast<int>(w < 1 ? 1 : w);
 }
 
-mpc_status mpc_encode_tiles_device(mpc_context* c, const uint8_t* d_rgb, int width, int height, size_t row_stride,
-                                   int tile_row_begin, int tile_row_end, const double* quant, uint16_t* d_counts,
-                                   mpc_basis_choice* d_choices, double* d_energy, uint32_t* d_swept, int waves,
-                                   void* stream) {
+mpc_status mpc_encode_batch_device(mpc_context* c, const uint8_t* d_rgb, int frames, size_t frame_stride, int width,
+                                   int height, size_t row_stride, int tile_row_begin, int tile_row_end,
+                                   const double* quant, uint16_t* d_counts, mpc_basis_choice* d_choices,
+                                   double* d_energy, uint32_t* d_swept, int waves, void* stream) {
     if (!c) return fail(MPC_ERR_ARGUMENT, "null context");
     if (c->device < 0) return fail(MPC_ERR_NO_DEVICE, "context was created without a device; there is no CPU fallback");
     if (!d_rgb || !d_counts || !d_choices) return fail(MPC_ERR_ARGUMENT, "null buffer");
@@ -185,8 +185,10 @@ mpc_status mpc_encode_tiles_device(mpc_context* c, const uint8_t* d_rgb, int wid
     const int tiles_x = (width + 7) / 8, tiles_y = (height + 7) / 8;
     if (tile_row_begin < 0 || tile_row_end > tiles_y || tile_row_begin >= tile_row_end)
         return fail(MPC_ERR_ARGUMENT, "tile rows [%d,%d) outside 0..%d", tile_row_begin, tile_row_end, tiles_y);
-    const long long tiles = static_cast<long long>(tiles_x) * (tile_row_end - tile_row_begin);
-    if (tiles * 3 >= (1LL << 31)) return fail(MPC_ERR_ARGUMENT, "stripe too large");
+    if (frames < 1 || (frames > 1 && frame_stride < row_stride * static_cast<size_t>(height)))
+        return fail(MPC_ERR_ARGUMENT, "bad batch: %d frames, stride %zu", frames, frame_stride);
+    const long long tiles = static_cast<long long>(tiles_x) * (tile_row_end - tile_row_begin) * frames;
+    if (tiles * 3 >= (1LL << 31)) return fail(MPC_ERR_ARGUMENT, "batch too large");
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (quant) HIP_TRY(hipMemcpyAsync(c->d_quant, quant, 3 * sizeof(double) * c->K, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemsetAsync(c->d_queue, 0, sizeof(unsigned), s));
@@ -196,6 +198,8 @@ mpc_status mpc_encode_tiles_device(mpc_context* c, const uint8_t* d_rgb, int wid
     p.width = width;
     p.height = height;
     p.row_stride = static_cast<long long>(row_stride);
+    p.frames = frames;
+    p.frame_stride = static_cast<long long>(frame_stride);
     p.tile_row_begin = tile_row_begin;
     p.tile_rows = tile_row_end - tile_row_begin;
     p.tiles_x = tiles_x;
@@ -218,6 +222,14 @@ mpc_status mpc_encode_tiles_device(mpc_context* c, const uint8_t* d_rgb, int wid
     const int err = mpc::launch_encode(p, pick_waves(c, tiles * 3, waves), stream);
     if (err != 0) return fail(MPC_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(err)));
     return MPC_OK;
+}
+
+mpc_status mpc_encode_tiles_device(mpc_context* c, const uint8_t* d_rgb, int width, int height, size_t row_stride,
+                                   int tile_row_begin, int tile_row_end, const double* quant, uint16_t* d_counts,
+                                   mpc_basis_choice* d_choices, double* d_energy, uint32_t* d_swept, int waves,
+                                   void* stream) {
+    return mpc_encode_batch_device(c, d_rgb, 1, 0, width, height, row_stride, tile_row_begin, tile_row_end, quant,
+                                   d_counts, d_choices, d_energy, d_swept, waves, stream);
 }
 
 mpc_status mpc_encode_tiles(mpc_context* c, const uint8_t* rgb, int width, int height, size_t row_stride,
@@ -325,6 +337,7 @@ mpc_status mpc_calc_mp_batch(mpc_context* c, int channel, const double* quant_k,
         p.energy = d_energy;
         p.swept = d_swept;
         p.queue = c->d_queue;
+        p.frames = 1;
         p.vec_in = d_in;
         p.vec_count = count;
         p.vec_channel = channel;

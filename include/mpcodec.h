@@ -13,6 +13,7 @@
  *                              createSegmentDictionary :299, createIntraSegmentDictionary :513)
  *   mpc_context_get/set_quant CompressionContext::{Y,U,V}.Quant           CompressedImage.h:22-36 (Compression.cpp:104-110
  *                                                                          overwrites them for "max" quality)
+ *   mpc_encode_batch_device   (same, several frames per launch)
  *   mpc_encode_tiles_device   the tile loop of compressed::encodeImage    CompressedImage.cpp:535-573, i.e. per tile
  *   mpc_encode_tiles          and channel: gather + img::YUVFromRGB (misc.cpp:7) + matching::CalcMPDynamic
  *                             (MatchingPursuit.h:22, MatchingPursuit.cpp:39) over compressed::dynamicBasis
@@ -102,6 +103,14 @@ mpc_status mpc_encode_tiles_device(mpc_context* ctx, const uint8_t* d_rgb, int w
                                    int tile_row_begin, int tile_row_end, const double* quant,
                                    uint16_t* d_counts, mpc_basis_choice* d_choices, double* d_energy, uint32_t* d_swept,
                                    int waves, void* stream);
+
+/* Batch form: `frames` equally sized frames, `frame_stride` bytes apart; the same tile rows of every frame are
+ * encoded in ONE launch (BASELINE config 4: batches of frames row-striped across GPUs).
+ * Output tile index t = frame * tiles_per_stripe + tx * rows + (ty - tile_row_begin). */
+mpc_status mpc_encode_batch_device(mpc_context* ctx, const uint8_t* d_rgb, int frames, size_t frame_stride,
+                                   int width, int height, size_t row_stride, int tile_row_begin, int tile_row_end,
+                                   const double* quant, uint16_t* d_counts, mpc_basis_choice* d_choices,
+                                   double* d_energy, uint32_t* d_swept, int waves, void* stream);
 
 /* Same with host buffers: uploads the frame, runs the kernel, copies the records back, synchronises. */
 mpc_status mpc_encode_tiles(mpc_context* ctx, const uint8_t* rgb, int width, int height, size_t row_stride,
