@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--waves", type=int, default=0, help="grid size in wave64 workgroups (0 = automatic)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-cols", type=int, default=160, help="tile columns in the CPU sample")
+    ap.add_argument("--phases", action="store_true", help="diagnostic: print per-phase shader clocks to stderr (untimed extra step)")
     args = ap.parse_args()
 
     import torch
@@ -163,6 +164,14 @@ def main():
     mac_lanes = 64 * swept_total                                         # f64 mul+add pairs executed per launch
     valu_gops = 2 * mac_lanes / (kernel_ms * 1e-3) / 1e9                # separate v_mul_f64 + v_add_f64
 
+    if args.phases:
+        ctx.enable_phase_profile(True)
+        step()
+        ph = ctx.read_phase_profile()
+        ctx.enable_phase_profile(False)
+        tot = sum(ph[k] for k in ("refill", "base_sweep", "detail_sweep", "finish")) or 1
+        print("[phases] " + ", ".join(f"{k}={ph[k] / tot:.3f}" for k in ("refill", "base_sweep", "detail_sweep", "finish"))
+              + f", wave-iterations={ph['iterations']}, clocks/iteration={tot / max(ph['iterations'], 1):.0f}", file=sys.stderr)
     if rank == 0:
         pixels_per_step = frames * W * H
         value = pixels_per_step * args.steps / elapsed / 1e6

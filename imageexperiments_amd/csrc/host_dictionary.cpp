@@ -499,7 +499,8 @@ void quantisation_tables(int K, int bs, double bpp, double* quant) {
 
 std::vector<double> base_padded(const Dictionary& d, int pad_rows, int* padded_rows) {
     const int rows = ((d.num_base + pad_rows - 1) / pad_rows) * pad_rows;
-    std::vector<double> out(static_cast<size_t>(rows) * d.n, 0.0);
+    // one more zero row than reported: the kernel's scalar prefetch reads one row past the last swept one
+    std::vector<double> out(static_cast<size_t>(rows + 1) * d.n, 0.0);
     std::copy(d.base.begin(), d.base.end(), out.begin());
     if (padded_rows) *padded_rows = rows;
     return out;

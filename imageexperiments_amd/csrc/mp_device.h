@@ -33,8 +33,15 @@ struct EncodeParams {
     uint32_t* choices;               // [tiles][3][K]  lo16 = deltaId, hi16 = intCoeff (BasisChoice layout)
     double* energy;                  // [tiles][3]  sum of squared residual at termination
     uint32_t* swept;                 // [tiles][3]  dictionary rows correlated (SURVEY 8d "S")
-    // work queue
-    unsigned int* queue;             // one counter, zeroed before the launch
+    // work queues: queue[0] hands out luma (Y) tile-channels, queue[1] chroma (U,V) ones; both zeroed before
+    // the launch.  Lanes < y_lanes of every wave prefer the Y queue, the others the chroma queue; a lane whose
+    // preferred queue is dry takes from the other one.  (Y pursuits run ~4x longer than chroma ones: starting
+    // all of them at once, spread over every wave, and streaming chroma through the remaining lanes is the
+    // longest-job-first schedule.)
+    unsigned int* queue;
+    int y_lanes;
+    // optional profiling: if non-null, per-phase shader-clock totals [refill, base sweep, detail sweep, finish, iterations]
+    unsigned long long* phase_cycles;
     // vector mode (matching::CalcMPDynamic on caller-supplied 64-vectors instead of image tiles):
     // when vec_in != nullptr the tasks are vec_count vectors of channel vec_channel, out index = vector index
     const double* vec_in;            // [vec_count][64]

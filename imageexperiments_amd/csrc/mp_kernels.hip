@@ -49,6 +49,20 @@ constexpr double W_R = 0.299, W_G = 0.587, W_B = 0.114;
 constexpr double U_SCALE = 0.436 / (1.0 - 0.114);
 constexpr double V_SCALE = 0.615 / (1.0 - 0.299);
 
+__device__ __forceinline__ void load_group(double (&g)[16], scalar_f64_ptr src) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) g[i] = src[i];
+}
+
+// one 16-coefficient group of the sequential dot product: tot += atom[j] * r[j], j ascending
+#define MAC_GROUP(cur, nxt, jbase, nextptr)                                              \
+    tot += cur[0] * r[jbase];                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+    load_group(nxt, nextptr);                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+    _Pragma("unroll") for (int i = 1; i < 16; ++i) tot += cur[i] * r[(jbase) + i];       \
+    __builtin_amdgcn_sched_barrier(0);
+
 __device__ __forceinline__ int wave_bcast_i32(int v, int src_lane) { return __builtin_amdgcn_readlane(v, src_lane); }
 
 }  // namespace
@@ -63,7 +77,11 @@ __global__ __launch_bounds__(64, 2) void mp_encode_kernel(const EncodeParams p)
     const bool vector_mode = p.vec_in != nullptr;
     const int ntiles = p.tiles_x * p.tile_rows;
     const int nunits = ntiles * p.frames;                 // tiles of the whole batch
-    const int ntasks = vector_mode ? p.vec_count : 3 * nunits;
+    const int n_y = vector_mode ? p.vec_count : nunits;   // tasks in the Y queue (vector mode: all of them)
+    const int n_uv = vector_mode ? 0 : 2 * nunits;        // tasks in the chroma queue
+    bool y_dry = false, uv_dry = (n_uv == 0);
+    unsigned long long cyc[4] = {0, 0, 0, 0};
+    unsigned iterations = 0;
     const scalar_f64_ptr base_s = (scalar_f64_ptr)(uintptr_t)p.base;
     const scalar_i32_ptr rows_s = (scalar_i32_ptr)(uintptr_t)p.block_rows;
     const scalar_i32_ptr rowoff_s = (scalar_i32_ptr)(uintptr_t)p.block_row_off;
@@ -84,16 +102,43 @@ __global__ __launch_bounds__(64, 2) void mp_encode_kernel(const EncodeParams p)
 
     for (;;) {
         // ------------------------------------------------------------------ refill idle lanes
-        {
+        unsigned long long t_phase = 0;
+        if (p.phase_cycles) t_phase = __builtin_readcyclecounter();
+#pragma unroll 1
+        for (int round = 0; round < 2; ++round) {
             const bool want = (task < 0) && !exhausted;
-            const unsigned long long m = __ballot(want);
-            if (m) {
-                int first = 0;
-                if (lane == 0) first = (int)atomicAdd(p.queue, (unsigned)__popcll(m));
-                first = wave_bcast_i32(first, 0);
-                if (want) {
-                    const int ticket = first + (int)__popcll(m & ((1ULL << lane) - 1ULL));
-                    if (ticket < ntasks) {
+            if (!__ballot(want)) break;
+            // queue choice: preferred one unless it is known dry
+            const bool prefer_y = lane < p.y_lanes;
+            const bool from_y = prefer_y ? !y_dry : uv_dry;
+            const bool from_uv = !from_y;
+            if (want && ((from_y && y_dry) || (from_uv && uv_dry))) exhausted = true;     // both queues dry
+            const bool ask = want && !exhausted;
+            const unsigned long long my = __ballot(ask && from_y);
+            const unsigned long long muv = __ballot(ask && from_uv);
+            int first_y = 0, first_uv = 0;
+            if (lane == 0) {
+                if (my) first_y = (int)atomicAdd(&p.queue[0], (unsigned)__popcll(my));
+                if (muv) first_uv = (int)atomicAdd(&p.queue[1], (unsigned)__popcll(muv));
+            }
+            first_y = wave_bcast_i32(first_y, 0);
+            first_uv = wave_bcast_i32(first_uv, 0);
+            const unsigned long long below = (1ULL << lane) - 1ULL;
+            int ticket = -1;
+            if (ask) {
+                if (from_y) {
+                    const int t = first_y + (int)__popcll(my & below);
+                    if (t < n_y) ticket = t;                       // Y queue: ticket = unit
+                } else {
+                    const int t = first_uv + (int)__popcll(muv & below);
+                    if (t < n_uv) ticket = n_y + t;                // chroma queue: U and V of a tile are neighbours
+                }
+            }
+            if (__ballot(ask && from_y && ticket < 0)) y_dry = true;      // wave-uniform knowledge
+            if (__ballot(ask && from_uv && ticket < 0)) uv_dry = true;
+            {
+                {
+                    if (ticket >= 0) {
                         task = ticket;
                         step = 0; prev_id = 0; nblk = 0; extra_rows = 0; swept = 0;
                         if (vector_mode) {
@@ -106,8 +151,9 @@ __global__ __launch_bounds__(64, 2) void mp_encode_kernel(const EncodeParams p)
                                 if ((j & 15) == 15) __builtin_amdgcn_sched_barrier(0);
                             }
                         } else {
-                        ch = ticket / nunits;                    // all Y first, then U, then V
-                        const int unit = ticket - ch * nunits;
+                        int unit;
+                        if (ticket < n_y) { ch = 0; unit = ticket; }
+                        else { ch = 1 + ((ticket - n_y) & 1); unit = (ticket - n_y) >> 1; }
                         const int frame = unit / ntiles;
                         const int tile = unit - frame * ntiles;
                         const int tx = tile / p.tile_rows;
@@ -135,30 +181,40 @@ __global__ __launch_bounds__(64, 2) void mp_encode_kernel(const EncodeParams p)
                             __builtin_amdgcn_sched_barrier(0);   // at most one pixel row of loads in flight (VGPR pressure)
                         }
                         }
-                    } else {
-                        exhausted = true;
                     }
                 }
             }
         }
         const bool active = task >= 0;
         if (!__ballot(active)) break;
+        unsigned long long t_now = 0;
+        if (p.phase_cycles) { t_now = __builtin_readcyclecounter(); cyc[0] += t_now - t_phase; t_phase = t_now; }
 
         // ------------------------------------------------------------------ mode A: base sweep
         double best_val = 0.0;      // Select(): bestCoeff = 0.0, index = -1
         int best_idx = -1;
         int best_sel = 0;           // where the winning row lives: ~idx for base, row index in `detail` otherwise
         {
+            // Software-pipelined scalar feed: the atom is consumed in four groups of 16 coefficients held in
+            // SGPRs.  SMEM returns out of order, so the only usable wait is lgkmcnt(0); therefore exactly one
+            // group load is kept in flight: the load of group g+1 is issued right after the wait for group g
+            // (i.e. after g's first multiply-add) and has 15 multiply-adds (and the co-resident wave's work)
+            // to land.  The row after the last one is a zero pad, so the trailing prefetch stays in bounds.
             scalar_f64_ptr atom = base_s;
+            double ga[16], gb[16];
+            load_group(ga, atom);
             for (int a = 0; a < p.base_rows_padded; ++a, atom += N) {
                 double tot = 0.0;
-#pragma unroll
-                for (int j = 0; j < N; ++j) tot += atom[j] * r[j];
+                MAC_GROUP(ga, gb, 0, atom + 16)
+                MAC_GROUP(gb, ga, 16, atom + 32)
+                MAC_GROUP(ga, gb, 32, atom + 48)
+                MAC_GROUP(gb, ga, 48, atom + 64)
                 if (__builtin_fabs(tot) > __builtin_fabs(best_val)) { best_val = tot; best_idx = a; }
             }
             best_sel = ~best_idx;
         }
 
+        if (p.phase_cycles) { t_now = __builtin_readcyclecounter(); cyc[1] += t_now - t_phase; t_phase = t_now; }
         // ------------------------------------------------------------------ mode B: per-tile-channel detail blocks
         {
             const bool has_blocks = active && nblk > 0;
@@ -231,6 +287,7 @@ __global__ __launch_bounds__(64, 2) void mp_encode_kernel(const EncodeParams p)
             }
         }
 
+        if (p.phase_cycles) { t_now = __builtin_readcyclecounter(); cyc[2] += t_now - t_phase; t_phase = t_now; }
         // ------------------------------------------------------------------ quantise, record, update (per lane)
         if (active) {
             swept += (unsigned)(p.num_base + extra_rows);
@@ -284,6 +341,12 @@ __global__ __launch_bounds__(64, 2) void mp_encode_kernel(const EncodeParams p)
                 task = -1;
             }
         }
+        ++iterations;
+        if (p.phase_cycles) { t_now = __builtin_readcyclecounter(); cyc[3] += t_now - t_phase; }
+    }
+    if (p.phase_cycles && lane == 0) {
+        for (int i = 0; i < 4; ++i) atomicAdd(&p.phase_cycles[i], cyc[i]);
+        atomicAdd(&p.phase_cycles[4], (unsigned long long)iterations);
     }
 }
 

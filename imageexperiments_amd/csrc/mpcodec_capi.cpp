@@ -55,6 +55,8 @@ struct mpc_context {
     int32_t* d_rows = nullptr;
     int32_t* d_rowoff = nullptr;
     unsigned* d_queue = nullptr;
+    unsigned long long* d_phase = nullptr;   // diagnostics: per-phase shader clocks (mpc_debug_*)
+    bool phase_enabled = false;
     int base_rows_padded = 0;
     int max_waves = 0;
 };
@@ -106,6 +108,8 @@ mpc_status mpc_context_create(int K, int block_size, double bpp, int device, mpc
         if (e == hipSuccess) e = upload(&c->d_rows, c->dict.block_rows.data(), c->dict.block_rows.size());
         if (e == hipSuccess) e = upload(&c->d_rowoff, c->dict.block_row_off.data(), c->dict.block_row_off.size());
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_queue), 64 * sizeof(unsigned));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_phase), 8 * sizeof(unsigned long long));
+        if (e == hipSuccess) e = hipMemset(c->d_phase, 0, 8 * sizeof(unsigned long long));
         if (e != hipSuccess) {
             mpc_context_destroy(c);
             return fail(MPC_ERR_HIP, "device setup failed: %s", hipGetErrorString(e));
@@ -127,6 +131,7 @@ void mpc_context_destroy(mpc_context* c) {
         (void)hipFree(c->d_rows);
         (void)hipFree(c->d_rowoff);
         (void)hipFree(c->d_queue);
+        (void)hipFree(c->d_phase);
     }
     delete c;
 }
@@ -173,6 +178,15 @@ static int pick_waves(const mpc_context* c, long long tasks, int requested) {
     return static_cast<int>(w < 1 ? 1 : w);
 }
 
+// lanes per wave that prefer the luma queue: enough for every Y pursuit to start in the first iteration,
+// spread evenly over the waves; all 64 when there are more Y tasks than lanes (pure longest-job-first).
+static int pick_y_lanes(long long y_tasks, int waves) {
+    long long per_wave = (y_tasks + waves - 1) / waves;
+    if (per_wave > 64) per_wave = 64;
+    if (per_wave < 1) per_wave = 1;
+    return static_cast<int>(per_wave);
+}
+
 mpc_status mpc_encode_batch_device(mpc_context* c, const uint8_t* d_rgb, int frames, size_t frame_stride, int width,
                                    int height, size_t row_stride, int tile_row_begin, int tile_row_end,
                                    const double* quant, uint16_t* d_counts, mpc_basis_choice* d_choices,
@@ -191,7 +205,7 @@ mpc_status mpc_encode_batch_device(mpc_context* c, const uint8_t* d_rgb, int fra
     if (tiles * 3 >= (1LL << 31)) return fail(MPC_ERR_ARGUMENT, "batch too large");
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (quant) HIP_TRY(hipMemcpyAsync(c->d_quant, quant, 3 * sizeof(double) * c->K, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemsetAsync(c->d_queue, 0, sizeof(unsigned), s));
+    HIP_TRY(hipMemsetAsync(c->d_queue, 0, 2 * sizeof(unsigned), s));
     HIP_TRY(hipMemsetAsync(d_choices, 0, sizeof(mpc_basis_choice) * tiles * 3 * c->K, s));
     mpc::EncodeParams p{};
     p.rgb = d_rgb;
@@ -219,7 +233,10 @@ mpc_status mpc_encode_batch_device(mpc_context* c, const uint8_t* d_rgb, int fra
     p.swept = d_swept;
     p.queue = c->d_queue;
     p.vec_in = nullptr;
-    const int err = mpc::launch_encode(p, pick_waves(c, tiles * 3, waves), stream);
+    const int nwaves = pick_waves(c, tiles * 3, waves);
+    p.y_lanes = pick_y_lanes(tiles, nwaves);
+    p.phase_cycles = c->phase_enabled ? c->d_phase : nullptr;
+    const int err = mpc::launch_encode(p, nwaves, stream);
     if (err != 0) return fail(MPC_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(err)));
     return MPC_OK;
 }
@@ -318,7 +335,7 @@ mpc_status mpc_calc_mp_batch(mpc_context* c, int channel, const double* quant_k,
     if (e == hipSuccess) e = hipMemcpy(d_in, inputs, sizeof(double) * 64 * count, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d_q, q.data(), sizeof(double) * 3 * K, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(d_choices, 0, sizeof(uint32_t) * count * K);
-    if (e == hipSuccess) e = hipMemset(c->d_queue, 0, sizeof(unsigned));
+    if (e == hipSuccess) e = hipMemset(c->d_queue, 0, 2 * sizeof(unsigned));
     int err = 0;
     if (e == hipSuccess) {
         mpc::EncodeParams p{};
@@ -341,6 +358,8 @@ mpc_status mpc_calc_mp_batch(mpc_context* c, int channel, const double* quant_k,
         p.vec_in = d_in;
         p.vec_count = count;
         p.vec_channel = channel;
+        p.y_lanes = 64;
+        p.phase_cycles = nullptr;
         err = mpc::launch_encode(p, pick_waves(c, count, 0), nullptr);
         if (err == 0) e = hipDeviceSynchronize();
         if (err == 0 && e == hipSuccess) e = hipMemcpy(counts, d_counts, sizeof(uint16_t) * count, hipMemcpyDeviceToHost);
@@ -357,6 +376,20 @@ mpc_status mpc_calc_mp_batch(mpc_context* c, int channel, const double* quant_k,
     (void)hipFree(d_q);
     if (err != 0) return fail(MPC_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(err)));
     if (e != hipSuccess) return fail(MPC_ERR_HIP, "HIP failure: %s", hipGetErrorString(e));
+    return MPC_OK;
+}
+
+void mpc_debug_enable_phases(mpc_context* c, int on) {
+    if (c) c->phase_enabled = on != 0;
+}
+
+mpc_status mpc_debug_read_phases(mpc_context* c, unsigned long long out[5], int reset) {
+    if (!c || !out) return fail(MPC_ERR_ARGUMENT, "null argument");
+    if (c->device < 0) return fail(MPC_ERR_NO_DEVICE, "context was created without a device");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, c->d_phase, 5 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (reset) HIP_TRY(hipMemset(c->d_phase, 0, 8 * sizeof(unsigned long long)));
     return MPC_OK;
 }
 

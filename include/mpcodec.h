@@ -132,6 +132,13 @@ mpc_status mpc_calc_mp(mpc_context* ctx, int channel, const double* quant_k, con
 mpc_status mpc_calc_mp_batch(mpc_context* ctx, int channel, const double* quant_k, const double* inputs, int count,
                              mpc_basis_choice* choices, uint16_t* counts, double* energy, uint32_t* swept);
 
+/* ---- diagnostics (profiling builds of a run; never changes results) ----------------------------------
+ * When enabled, every wave of the encode kernel adds its shader-clock time per phase to a context-owned
+ * buffer: out[0] refill, out[1] base sweep, out[2] detail sweep, out[3] quantise/update, out[4] = wave
+ * iterations.  mpc_debug_read_phases synchronises the device. */
+void mpc_debug_enable_phases(mpc_context* ctx, int on);
+mpc_status mpc_debug_read_phases(mpc_context* ctx, unsigned long long out[5], int reset);
+
 #ifdef __cplusplus
 }
 #endif
