@@ -88,7 +88,6 @@ def main():
     ap.add_argument("--waves", type=int, default=0, help="grid size in wave64 workgroups (0 = automatic)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-cols", type=int, default=160, help="tile columns in the CPU sample")
-    ap.add_argument("--phases", action="store_true", help="diagnostic: print per-phase shader clocks to stderr (untimed extra step)")
     args = ap.parse_args()
 
     import torch
@@ -123,6 +122,7 @@ def main():
     d_energy = torch.zeros((tiles, 3), dtype=torch.float64, device="cuda")
     d_swept = torch.zeros((tiles, 3), dtype=torch.int32, device="cuda")
     d_hist = torch.zeros((1 + 6 * K, ia.api.HIST_BINS), dtype=torch.int32, device="cuda")
+    ctx.reserve(tiles)
     stream = torch.cuda.current_stream()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
@@ -164,14 +164,6 @@ def main():
     mac_lanes = 64 * swept_total                                         # f64 mul+add pairs executed per launch
     valu_gops = 2 * mac_lanes / (kernel_ms * 1e-3) / 1e9                # separate v_mul_f64 + v_add_f64
 
-    if args.phases:
-        ctx.enable_phase_profile(True)
-        step()
-        ph = ctx.read_phase_profile()
-        ctx.enable_phase_profile(False)
-        tot = sum(ph[k] for k in ("refill", "base_sweep", "detail_sweep", "finish")) or 1
-        print("[phases] " + ", ".join(f"{k}={ph[k] / tot:.3f}" for k in ("refill", "base_sweep", "detail_sweep", "finish"))
-              + f", wave-iterations={ph['iterations']}, clocks/iteration={tot / max(ph['iterations'], 1):.0f}", file=sys.stderr)
     if rank == 0:
         pixels_per_step = frames * W * H
         value = pixels_per_step * args.steps / elapsed / 1e6
@@ -200,10 +192,10 @@ def main():
                        "stage": "device tile encode: RGB in HBM -> per-tile MP records + symbol histograms in HBM"
                                 + (" + RCCL all-reduce of the histograms" if world > 1 else "")
                                 + "; host entropy stage (byte-identical container) not in the timed region",
-                       "tiles_per_rank": tiles, "waves": args.waves or ctx.max_waves},
+                       "tiles_per_rank": tiles},
             "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "mp_encode_kernel", "kernel_ms": round(kernel_ms, 4),
+                         "kernel": "mp_base_kernel (dominant of the per-step sequence; kernel_ms = whole K-step pursuit)", "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes_per_launch": sweep_bytes, "swept_rows_per_tile": round(swept_total / tiles, 1),
                          "note": "algorithmic sweep bytes = 64*8*S (SURVEY 8d); the dictionary is served by the scalar "
                                  "cache/L2, so this exceeds real HBM traffic by design; the binding unit is f64 VALU issue",

@@ -69,8 +69,7 @@ def load_library():
     L.mpc_histogram_device.argtypes = [vp, vp, vp, C.c_longlong, vp, vp]
     L.mpc_calc_mp.argtypes = [vp, C.c_int, _dp, _dp, vp, C.POINTER(C.c_int)]
     L.mpc_calc_mp_batch.argtypes = [vp, C.c_int, _dp, _dp, C.c_int, vp, _u16p, _dp, _u32p]
-    L.mpc_debug_enable_phases.argtypes = [vp, C.c_int]
-    L.mpc_debug_read_phases.argtypes = [vp, C.POINTER(C.c_ulonglong), C.c_int]
+    L.mpc_reserve.argtypes = [vp, C.c_longlong]
     _bind_bitstream(L)
     _lib = L
     return L
@@ -210,14 +209,9 @@ class CompressionContext:
     def histogram_device(self, d_counts, d_choices, tiles, d_hist, stream=0):
         _check(self.L.mpc_histogram_device(self.h, d_counts, d_choices, tiles, d_hist, stream or None))
 
-    def enable_phase_profile(self, on=True):
-        self.L.mpc_debug_enable_phases(self.h, 1 if on else 0)
-
-    def read_phase_profile(self, reset=True):
-        """-> dict of shader-clock totals per kernel phase (diagnostics)."""
-        out = (C.c_ulonglong * 5)()
-        _check(self.L.mpc_debug_read_phases(self.h, out, 1 if reset else 0))
-        return dict(refill=out[0], base_sweep=out[1], detail_sweep=out[2], finish=out[3], iterations=out[4])
+    def reserve(self, max_tiles):
+        """Pre-allocate the device workspace for calls of up to `max_tiles` tiles."""
+        _check(self.L.mpc_reserve(self.h, int(max_tiles)))
 
     def calc_mp(self, channel, vectors, quant_k=None):
         """matching::CalcMPDynamic (MatchingPursuit.h:22) on the device for vectors[n,64].

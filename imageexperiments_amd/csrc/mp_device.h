@@ -1,52 +1,90 @@
-// mp_device.h -- product: device-side parameter block and launchers for the
-// MI355X (gfx950) quantized matching-pursuit tile encoder.
+// mp_device.h -- product: device-side data layout and launchers of the MI355X (gfx950)
+// quantized matching-pursuit tile encoder.
+//
+// The pursuit is run STEP-SYNCHRONOUSLY over a batch of tile-channels (one 8x8 tile of one of Y/U/V):
+// every MP step is a short sequence of kernels over the tile-channels that are still active.
+//
+//   init      gather tile + YUVFromRGB -> residual r[tc][64], reset state        (CompressedImage.cpp:538-554)
+//   per step s = 0..K-1:
+//     bucket   (s>0) prefix-sum the per-block item counts, emit chunk descriptors
+//     fill     (s>0) scatter (tile-channel, block) items into their block's bucket
+//     base     correlate r with the 510 shared base atoms                          (Select, MatchingPursuit.cpp:7-25)
+//     detail0  (s>0) correlate r with DetailBasis[0] (the DC block nearly every tile unlocks first)
+//     detail   (s>0) correlate r with every other unlocked detail block, bucketed by block
+//     finish   argmax in dictionary order, quantise, record, residual update, unlock block, compact
+//                                                                                   (MatchingPursuit.cpp:55-71)
+// Why this shape: the base atoms are common to all tile-channels, so `base` keeps 64 residuals in the VGPRs of
+// a wave (lane = tile-channel) and streams the atoms as wave-uniform scalars; the detail blocks differ per
+// tile-channel, so `detail` does the opposite -- a wave keeps one block's 62/63 atom rows in VGPRs (lane =
+// atom row) and streams the residuals of all tile-channels that unlocked that block as wave-uniform scalars.
+// Either way each multiply-add takes one s_load'ed double and one VGPR double: no LDS or L2 traffic per MAC,
+// and every dot product stays the reference's sequential tot += l*r.
 #pragma once
 #include <cstddef>
 #include <cstdint>
 
 namespace mpc {
 
-// One launch = one stripe of tile rows of one RGB frame.
-struct EncodeParams {
-    // input frame (device memory), row-major, 3 B/pixel (img::image<rgb>, image.h:123-131)
-    const uint8_t* rgb;
-    int width, height;
-    long long row_stride;            // bytes between image rows
-    int frames;                      // batch of equally sized frames, `frame_stride` bytes apart
-    long long frame_stride;
-    // stripe of tile rows handled by this launch
-    int tile_row_begin, tile_rows;   // rows [begin, begin+tile_rows)
-    int tiles_x;
-    int K;                           // MP steps (<= 32)
-    // dictionary (device memory)
-    const double* base;              // [base_rows_padded][64] row-major (rows >= num_base are zero)
+constexpr int kHistBins = 8192;
+constexpr int kMaxDeviceK = 32;
+constexpr int kMaxParts = 8;            // base sweep can be split over up to 8 atom ranges per tile-channel group
+constexpr int kChunkItems = 64;         // items (tile-channels) a wave processes per loaded detail block
+constexpr int kNumBuckets = 3 * 512;    // (channel, block) buckets, block < 510
+
+struct DictDevice {
+    const double* base;              // [base_rows_padded + 1][64] row-major, zero rows after num_base
     int num_base;                    // 510
-    int base_rows_padded;            // multiple of 2
+    int base_rows_padded;
     const double* detail;            // [3][detail_rows][64] row-major
     const double* detail_t;          // [3][num_base][32][64][2] transposed + padded blocks
     long long detail_rows;           // rows per channel (31 622)
     const int32_t* block_rows;       // [num_base]
     const int32_t* block_row_off;    // [num_base+1]
-    const double* quant;             // [3][K] (device memory)
-    // outputs (device memory); tile index t = frame*tiles + tx*tile_rows + (ty - tile_row_begin)
-    uint16_t* counts;                // [tiles][3]
-    uint32_t* choices;               // [tiles][3][K]  lo16 = deltaId, hi16 = intCoeff (BasisChoice layout)
-    double* energy;                  // [tiles][3]  sum of squared residual at termination
-    uint32_t* swept;                 // [tiles][3]  dictionary rows correlated (SURVEY 8d "S")
-    // work queues: queue[0] hands out luma (Y) tile-channels, queue[1] chroma (U,V) ones; both zeroed before
-    // the launch.  Lanes < y_lanes of every wave prefer the Y queue, the others the chroma queue; a lane whose
-    // preferred queue is dry takes from the other one.  (Y pursuits run ~4x longer than chroma ones: starting
-    // all of them at once, spread over every wave, and streaming chroma through the remaining lanes is the
-    // longest-job-first schedule.)
-    unsigned int* queue;
-    int y_lanes;
-    // optional profiling: if non-null, per-phase shader-clock totals [refill, base sweep, detail sweep, finish, iterations]
-    unsigned long long* phase_cycles;
-    // vector mode (matching::CalcMPDynamic on caller-supplied 64-vectors instead of image tiles):
-    // when vec_in != nullptr the tasks are vec_count vectors of channel vec_channel, out index = vector index
-    const double* vec_in;            // [vec_count][64]
-    int vec_count;
+};
+
+// Per-batch device workspace (all device pointers). cap = max tile-channels per batch.
+struct Workspace {
+    int cap;
+    double* r;                       // [cap][64] residuals
+    double* part_val;                // [cap][kMaxParts] best projection of each base atom range
+    int* part_idx;                   // [cap][kMaxParts]
+    int* prev_id;                    // [cap]
+    int* nblk;                       // [cap] entries in blk_list
+    int* extra_rows;                 // [cap] rows appended after the base part (duplicates included)
+    unsigned* swept;                 // [cap]
+    uint16_t* blk_list;              // [cap][32] chosen base atoms in order, bit 15 = repeat of an earlier entry
+    int* item_slot;                  // [cap][32] bucket slot of each blk_list entry for the current step
+    int* out_index;                  // [cap] record index (unit*3 + channel) in the caller's outputs
+    int* act[2];                     // [cap] active tile-channel lists (ping-pong)
+    unsigned* counters;              // [16]: 0,1 = n_act ping-pong; 2 = chunk cursor; 3 = n_chunks; 4 = n_items
+    unsigned* bucket_count[2];       // [kNumBuckets] items per (channel, block) for this / the next step
+    unsigned* bucket_start;          // [kNumBuckets + 1]
+    unsigned* bucket_cursor;         // [kNumBuckets]
+    int* chunks;                     // [max_chunks][4] = bucket, begin, end, 0
+    int* items;                      // [max_items] tile-channel of each item
+    double* proj;                    // [max_items][64] projections of the item's block rows
+    double* proj0;                   // [cap][64] projections on DetailBasis[0], indexed by position in act list
+    long long max_items;
+    int max_chunks;
+};
+
+struct FrameInput {
+    const uint8_t* rgb;              // device, row-major, 3 B/pixel (img::image<rgb>, image.h:123-131)
+    int width, height;
+    long long row_stride;
+    int frames;
+    long long frame_stride;
+    int tile_row_begin, tile_rows, tiles_x;
+    // vector mode (matching::CalcMPDynamic on caller vectors): vec_in != nullptr
+    const double* vec_in;            // [n][64]
     int vec_channel;
+};
+
+struct Outputs {
+    uint16_t* counts;                // [records]
+    uint32_t* choices;               // [records][K]  lo16 = deltaId, hi16 = intCoeff
+    double* energy;                  // [records] or null
+    uint32_t* swept;                 // [records] or null
 };
 
 struct HistParams {
@@ -57,15 +95,18 @@ struct HistParams {
     uint32_t* hist;                  // [(1 + 6K)][8192]
 };
 
-constexpr int kHistBins = 8192;
-constexpr int kMaxDeviceK = 32;
+// Enqueue the whole K-step pursuit for the tile-channels [tc_begin, tc_begin + n) of the input on `stream`.
+// Tile-channel numbering: tc = unit*3 + ch, unit = frame*tiles_per_frame_stripe + tx*tile_rows + (ty - begin)
+// (vector mode: tc = vector index, channel fixed).  Returns hipError_t as int.  No host synchronisation,
+// no allocation: graph-capturable.
+int enqueue_pursuit(const DictDevice& dict, const Workspace& ws, const FrameInput& in, const Outputs& out,
+                    const double* quant_dev, int K, long long tc_begin, int n, int parts, void* stream);
 
-// Launch the encoder on `stream` (hipStream_t as void*). `waves` = grid size (one wave64 per workgroup).
-// Returns hipError_t as int.
-int launch_encode(const EncodeParams& p, int waves, void* stream);
 int launch_histogram(const HistParams& p, void* stream);
 
-// resident-wave capacity for the encode kernel on the current device
-int encode_max_resident_waves();
+// bytes of workspace needed for `cap` tile-channels and K steps
+size_t workspace_bytes(int cap, int K);
+// carve a workspace out of one device allocation of workspace_bytes(cap, K) bytes
+Workspace carve_workspace(void* device_mem, int cap, int K);
 
 }  // namespace mpc

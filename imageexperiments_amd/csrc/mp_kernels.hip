@@ -1,0 +1,554 @@
+// mp_kernels.hip -- product: hand-written gfx950 (CDNA4, wave64) kernels of the quantized
+// matching-pursuit tile encoder.  See mp_device.h for the pipeline.  No MFMA; IEEE double with
+// separately rounded mul/add (-ffp-contract=off): integer outputs must equal the reference's
+// double path (MatchingPursuit.cpp:39-74) bit for bit.
+//
+// The two sweep kernels share one inner loop shape: a 64-term sequential dot product
+//     tot = 0; tot += a[j] * b[j]   (j ascending, mathmatrix.cpp:436-444)
+// where one operand lives in 128 VGPRs for the whole loop and the other is wave-uniform and arrives
+// through the scalar data cache (s_load_dwordx16 -> SGPR operand of v_mul_f64).  SMEM returns out of
+// order, so the only usable wait is lgkmcnt(0): the loop keeps exactly ONE 16-double group load in
+// flight, issued right after the wait for the previous group, and relies on 2-3 co-resident waves per
+// SIMD to cover what 15 multiply-adds do not (measured: tools/ubench_scalar_sweep.hip).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mp_device.h"
+
+namespace mpc {
+
+namespace {
+
+typedef const double __attribute__((address_space(4))) * scalar_f64_ptr;   // constant address space: forces s_load
+typedef const uint32_t __attribute__((address_space(4))) * scalar_u32_ptr;
+
+constexpr int N = 64;                  // pixels per tile
+
+// YUV weights, ImageHelper/inc/misc.h:7-11; folded in double exactly like the reference's macros
+constexpr double W_R = 0.299, W_G = 0.587, W_B = 0.114;
+constexpr double U_SCALE = 0.436 / (1.0 - 0.114);
+constexpr double V_SCALE = 0.615 / (1.0 - 0.299);
+
+__device__ __forceinline__ void load_group(double (&g)[16], scalar_f64_ptr src) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) g[i] = src[i];
+}
+
+// one 16-term group of the sequential dot product; `cur` = scalar group in SGPRs, `vec` = the VGPR operand
+#define MAC_GROUP(cur, nxt, vec, jbase, nextptr)                                         \
+    tot += cur[0] * vec[jbase];                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+    load_group(nxt, nextptr);                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+    _Pragma("unroll") for (int i = 1; i < 16; ++i) tot += cur[i] * vec[(jbase) + i];     \
+    __builtin_amdgcn_sched_barrier(0);
+
+__device__ __forceinline__ scalar_f64_ptr as_scalar(const double* p) { return (scalar_f64_ptr)(uintptr_t)p; }
+
+}  // namespace
+
+// --------------------------------------------------------------------------------------------------
+// init: one thread per tile-channel.  Gathers the 8x8 tile (zero outside the image), converts to the
+// channel's YUV component (misc.cpp:12-21) and resets the pursuit state.
+// --------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mp_init_kernel(const Workspace ws, const FrameInput in, long long tc_begin, int n)
+{
+    const int tc = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x == 0) {
+        for (int b = threadIdx.x; b < kNumBuckets; b += blockDim.x) {
+            ws.bucket_count[0][b] = 0;
+            ws.bucket_count[1][b] = 0;
+        }
+        if (threadIdx.x == 0) {
+            ws.counters[0] = (unsigned)n;
+            ws.counters[1] = 0;
+        }
+    }
+    if (tc >= n) return;
+    const long long gtc = tc_begin + tc;
+    double* r = ws.r + (long long)tc * N;
+    int ch;
+    if (in.vec_in) {
+        ch = in.vec_channel;
+        const double* v = in.vec_in + gtc * N;
+        for (int j = 0; j < N; ++j) r[j] = v[j];
+    } else {
+        const long long unit = gtc / 3;
+        ch = (int)(gtc - unit * 3);
+        const int tiles_per_frame = in.tiles_x * in.tile_rows;
+        const int frame = (int)(unit / tiles_per_frame);
+        const int tile = (int)(unit - (long long)frame * tiles_per_frame);
+        const int tx = tile / in.tile_rows;
+        const int ty = in.tile_row_begin + (tile - tx * in.tile_rows);
+        const uint8_t* frame_rgb = in.rgb + (long long)frame * in.frame_stride;
+        const int x0 = tx * 8, y0 = ty * 8;
+        for (int dy = 0; dy < 8; ++dy) {
+            const int v = y0 + dy;
+            for (int dx = 0; dx < 8; ++dx) {
+                const int u = x0 + dx;
+                double val = 0.0;                                       // zero fill outside (CompressedImage.cpp:548-552)
+                if (u < in.width && v < in.height) {
+                    const uint8_t* px = frame_rgb + (long long)v * in.row_stride + 3 * u;
+                    const double red = (double)px[0], green = (double)px[1], blue = (double)px[2];
+                    const double Y = (W_R * red + W_G * green + W_B * blue);
+                    val = (ch == 0) ? Y : ((ch == 1) ? (U_SCALE * (blue - Y)) : (V_SCALE * (red - Y)));
+                }
+                r[dx + 8 * dy] = val;
+            }
+        }
+    }
+    ws.prev_id[tc] = 0;
+    ws.nblk[tc] = 0;
+    ws.extra_rows[tc] = 0;
+    ws.swept[tc] = 0;
+    ws.out_index[tc] = (int)((unsigned)gtc | ((unsigned)ch << 30));    // record index in the low 30 bits, channel on top
+    ws.act[0][tc] = tc;
+}
+
+// --------------------------------------------------------------------------------------------------
+// base sweep: one wave = 64 active tile-channels (lane = tile-channel, residual in 128 VGPRs) x one
+// range of base atoms (wave-uniform, scalar-fed).  Writes the best projection of the range; ranges are
+// combined in index order by the finish kernel.
+// --------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64, 3) void mp_base_kernel(const Workspace ws, const DictDevice dict, int cur, int parts)
+{
+    const int lane = threadIdx.x;
+    const int group = blockIdx.x / parts;
+    const int part = blockIdx.x - group * parts;
+    if (blockIdx.x == 0 && lane == 0) ws.counters[cur ^ 1] = 0;          // next step's active count
+    const int n_act = (int)((scalar_u32_ptr)(uintptr_t)ws.counters)[cur];
+    if (group * 64 >= n_act) return;
+    const int pos = group * 64 + lane;
+    const bool valid = pos < n_act;
+    const int tc = ws.act[cur][valid ? pos : group * 64];
+
+    double r[N];
+    {
+        const double2* src = (const double2*)(ws.r + (long long)tc * N);
+#pragma unroll
+        for (int jj = 0; jj < N / 2; ++jj) {
+            const double2 v = src[jj];
+            r[2 * jj] = v.x;
+            r[2 * jj + 1] = v.y;
+        }
+    }
+    const int per = (dict.base_rows_padded + parts - 1) / parts;
+    const int a0 = part * per;
+    const int a1 = (a0 + per < dict.base_rows_padded) ? a0 + per : dict.base_rows_padded;
+
+    double best_val = 0.0;      // Select(): bestCoeff = 0.0, index = -1 (MatchingPursuit.cpp:9-10)
+    int best_idx = -1;
+    scalar_f64_ptr atom = as_scalar(dict.base) + (long long)a0 * N;
+    double ga[16], gb[16];
+    load_group(ga, atom);
+    for (int a = a0; a < a1; ++a, atom += N) {
+        double tot = 0.0;
+        MAC_GROUP(ga, gb, r, 0, atom + 16)
+        MAC_GROUP(gb, ga, r, 16, atom + 32)
+        MAC_GROUP(ga, gb, r, 32, atom + 48)
+        MAC_GROUP(gb, ga, r, 48, atom + 64)          // row after the last is a zero pad: stays in bounds
+        if (__builtin_fabs(tot) > __builtin_fabs(best_val)) { best_val = tot; best_idx = a; }
+    }
+    if (valid) {
+        ws.part_val[(long long)tc * kMaxParts + part] = best_val;
+        ws.part_idx[(long long)tc * kMaxParts + part] = best_idx;
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
+// detail sweeps: one wave keeps the 62/63 rows of ONE detail block in VGPRs (lane = atom row, rows >=
+// block_rows are zero) and streams tile-channel residuals as scalars.  All 64 projections of an item
+// are stored; the finish kernel scans them in dictionary order.
+// --------------------------------------------------------------------------------------------------
+namespace {
+
+__device__ __forceinline__ void load_block_rows(double (&row)[N], const double* detail_t, long long block, int lane)
+{
+    const double2* src = (const double2*)detail_t + block * (N / 2) * 64 + lane;
+#pragma unroll
+    for (int jj = 0; jj < N / 2; ++jj) {
+        const double2 v = src[jj * 64];
+        row[2 * jj] = v.x;
+        row[2 * jj + 1] = v.y;
+    }
+}
+
+// items: bit mask `todo` over 64 candidate slots; tc of slot p is lane p's `tc_lane`; results to dst + p*64
+__device__ __forceinline__ void sweep_items(const double (&row)[N], unsigned long long todo, int tc_lane,
+                                            const double* r_all, double* dst, int lane)
+{
+    if (!todo) return;
+    int p = __builtin_ctzll(todo);
+    todo &= todo - 1;
+    const int tc0 = __builtin_amdgcn_readlane(tc_lane, p);
+    scalar_f64_ptr res = as_scalar(r_all) + (long long)tc0 * N;
+    double ga[16], gb[16];
+    load_group(ga, res);
+    for (;;) {
+        // look ahead: the residual of the next item (or this one again, harmlessly, when it is the last)
+        const bool more = todo != 0;
+        const int pn = more ? __builtin_ctzll(todo) : p;
+        const int tcn = __builtin_amdgcn_readlane(tc_lane, pn);
+        scalar_f64_ptr resn = as_scalar(r_all) + (long long)tcn * N;
+        double tot = 0.0;
+        MAC_GROUP(ga, gb, row, 0, res + 16)
+        MAC_GROUP(gb, ga, row, 16, res + 32)
+        MAC_GROUP(ga, gb, row, 32, res + 48)
+        MAC_GROUP(gb, ga, row, 48, resn)
+        dst[(long long)p * N + lane] = tot;
+        if (!more) break;
+        todo &= todo - 1;
+        p = pn;
+        res = resn;
+    }
+}
+
+}  // namespace
+
+// DetailBasis[0] (unlocked by the DC atom, i.e. by nearly every tile-channel at step 0): no bucketing, the
+// wave walks 64 consecutive entries of the active list and takes those of its channel that hold block 0.
+__global__ __launch_bounds__(64, 3) void mp_detail0_kernel(const Workspace ws, const DictDevice dict, int cur)
+{
+    const int lane = threadIdx.x;
+    const int group = blockIdx.x / 3;
+    const int ch = blockIdx.x - group * 3;
+    const int n_act = (int)((scalar_u32_ptr)(uintptr_t)ws.counters)[cur];
+    if (group * 64 >= n_act) return;
+    const int pos = group * 64 + lane;
+    int tc = 0;
+    bool mine = false;
+    if (pos < n_act) {
+        tc = ws.act[cur][pos];
+        const int nb = ws.nblk[tc];
+        if (((unsigned)ws.out_index[tc] >> 30) == (unsigned)ch) {
+            for (int i = 0; i < nb; ++i)
+                if (ws.blk_list[(long long)tc * kMaxDeviceK + i] == 0) mine = true;     // first occurrence of block 0
+        }
+    }
+    const unsigned long long todo = __ballot(mine);
+    if (!todo) return;
+    double row[N];
+    load_block_rows(row, dict.detail_t, (long long)ch * dict.num_base + 0, lane);
+    sweep_items(row, todo, tc, ws.r, ws.proj0 + (long long)group * 64 * N, lane);
+}
+
+// every other block: chunks of <= 64 items of one (channel, block) bucket, pulled from a device-side cursor
+__global__ __launch_bounds__(64, 3) void mp_detail_kernel(const Workspace ws, const DictDevice dict)
+{
+    const int lane = threadIdx.x;
+    const unsigned n_chunks = ((scalar_u32_ptr)(uintptr_t)ws.counters)[3];
+    for (;;) {
+        unsigned c = 0;
+        if (lane == 0) c = atomicAdd(&ws.counters[2], 1u);
+        c = (unsigned)__builtin_amdgcn_readfirstlane((int)c);
+        if (c >= n_chunks) break;
+        const int bucket = ws.chunks[4 * (long long)c + 0];
+        const int begin = ws.chunks[4 * (long long)c + 1];
+        const int end = ws.chunks[4 * (long long)c + 2];
+        const int ch = bucket >> 9, blk = bucket & 511;
+        const int cnt = end - begin;
+        int tc = 0;
+        if (lane < cnt) tc = ws.items[begin + lane];
+        double row[N];
+        load_block_rows(row, dict.detail_t, (long long)ch * dict.num_base + blk, lane);
+        const unsigned long long todo = (cnt >= 64) ? ~0ULL : ((1ULL << cnt) - 1ULL);
+        sweep_items(row, todo, tc, ws.r, ws.proj + (long long)begin * N, lane);
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
+// bucket: exclusive scan of the per-(channel, block) item counts, chunk descriptors, counter resets.
+// One workgroup of 1024 threads; 1536 buckets.
+// --------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void mp_bucket_kernel(const Workspace ws, int cur_cnt)
+{
+    __shared__ unsigned s_items[2048];
+    __shared__ unsigned s_chunks[2048];
+    const int t = threadIdx.x;
+    const unsigned* cnt = ws.bucket_count[cur_cnt];
+    unsigned* nxt = ws.bucket_count[cur_cnt ^ 1];
+    for (int b = t; b < 2048; b += 1024) {
+        const unsigned c = (b < kNumBuckets) ? cnt[b] : 0u;
+        s_items[b] = c;
+        s_chunks[b] = (c + kChunkItems - 1) / kChunkItems;
+    }
+    __syncthreads();
+    // Hillis-Steele inclusive scan over 2048 entries, two per thread
+    for (int d = 1; d < 2048; d <<= 1) {
+        unsigned a0 = 0, a1 = 0, c0 = 0, c1 = 0;
+        const int i0 = t, i1 = t + 1024;
+        if (i0 >= d) { a0 = s_items[i0 - d]; c0 = s_chunks[i0 - d]; }
+        if (i1 >= d) { a1 = s_items[i1 - d]; c1 = s_chunks[i1 - d]; }
+        __syncthreads();
+        s_items[i0] += a0; s_chunks[i0] += c0;
+        s_items[i1] += a1; s_chunks[i1] += c1;
+        __syncthreads();
+    }
+    for (int b = t; b < kNumBuckets; b += 1024) {
+        const unsigned c = cnt[b];
+        const unsigned start = s_items[b] - c;                 // exclusive
+        const unsigned nch = (c + kChunkItems - 1) / kChunkItems;
+        const unsigned coff = s_chunks[b] - nch;
+        ws.bucket_start[b] = start;
+        ws.bucket_cursor[b] = 0;
+        nxt[b] = 0;
+        for (unsigned k = 0; k < nch; ++k) {
+            const unsigned lo = start + k * kChunkItems;
+            const unsigned hi = (lo + kChunkItems < start + c) ? lo + kChunkItems : start + c;
+            int* d = ws.chunks + 4 * (long long)(coff + k);
+            d[0] = b; d[1] = (int)lo; d[2] = (int)hi; d[3] = 0;
+        }
+    }
+    if (t == 0) {
+        ws.bucket_start[kNumBuckets] = s_items[kNumBuckets - 1];
+        ws.counters[2] = 0;                                     // chunk cursor
+        ws.counters[3] = s_chunks[kNumBuckets - 1];             // chunks this step
+        ws.counters[4] = s_items[kNumBuckets - 1];              // items this step
+    }
+}
+
+// fill: each active tile-channel drops one item per unlocked, non-repeated block (block 0 excepted) into
+// that block's bucket and remembers the slot.
+__global__ __launch_bounds__(256) void mp_fill_kernel(const Workspace ws, int cur)
+{
+    const int n_act = (int)ws.counters[cur];
+    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= n_act) return;
+    const int tc = ws.act[cur][pos];
+    const int ch = (int)((unsigned)ws.out_index[tc] >> 30);
+    const int nb = ws.nblk[tc];
+    for (int i = 0; i < nb; ++i) {
+        const unsigned e = ws.blk_list[(long long)tc * kMaxDeviceK + i];
+        if (e == 0 || (e & 0x8000u)) continue;
+        const int b = (ch << 9) | (int)e;
+        const unsigned slot = ws.bucket_start[b] + atomicAdd(&ws.bucket_cursor[b], 1u);
+        ws.items[slot] = tc;
+        ws.item_slot[(long long)tc * kMaxDeviceK + i] = (int)slot;
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
+// finish: per active tile-channel -- argmax over the whole dynamic dictionary in index order (strict '>',
+// first maximum wins: MatchingPursuit.cpp:14-19), delta/zigzag, quantise, record, residual update
+// (mathvector.cpp:116-148), unlock DetailBasis[choice] (CompressedImage.cpp:226-229), termination.
+// --------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mp_finish_kernel(const Workspace ws, const DictDevice dict, const Outputs out,
+                                                       const double* __restrict__ quant, int K, int step, int cur,
+                                                       int parts)
+{
+    const int n_act = (int)ws.counters[cur];
+    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= n_act) return;
+    const int tc = ws.act[cur][pos];
+    const unsigned oi = (unsigned)ws.out_index[tc];
+    const int ch = (int)(oi >> 30);
+    const long long rec = (long long)(oi & 0x3FFFFFFFu);
+    const int nb = ws.nblk[tc];
+    const int extra = ws.extra_rows[tc];
+
+    double best_val = 0.0;
+    int best_idx = -1;
+    int best_sel = 0;                       // ~idx for a base atom, row index into `detail` otherwise
+    for (int p = 0; p < parts; ++p) {
+        const double v = ws.part_val[(long long)tc * kMaxParts + p];
+        const int i = ws.part_idx[(long long)tc * kMaxParts + p];
+        if (i >= 0 && __builtin_fabs(v) > __builtin_fabs(best_val)) { best_val = v; best_idx = i; best_sel = ~i; }
+    }
+    int off = dict.num_base;
+    for (int i = 0; i < nb; ++i) {
+        const unsigned e = ws.blk_list[(long long)tc * kMaxDeviceK + i];
+        const int blk = (int)(e & 0x7FFFu);
+        const int rows = dict.block_rows[blk];
+        if (!(e & 0x8000u)) {               // a repeated block can never win: identical projections at a higher index
+            const double* pr = (blk == 0) ? (ws.proj0 + (long long)pos * N)
+                                          : (ws.proj + (long long)ws.item_slot[(long long)tc * kMaxDeviceK + i] * N);
+            for (int row = 0; row < rows; ++row) {
+                const double v = pr[row];
+                if (__builtin_fabs(v) > __builtin_fabs(best_val)) {
+                    best_val = v; best_idx = off + row; best_sel = dict.block_row_off[blk] + row;
+                }
+            }
+        }
+        off += rows;
+    }
+    const unsigned swept = ws.swept[tc] + (unsigned)(dict.num_base + extra);
+    ws.swept[tc] = swept;
+
+    double* r = ws.r + (long long)tc * N;
+    bool done = false;
+    int count = 0;
+    unsigned record = 0;
+    bool unlocked = false;
+    if (best_idx < 0) {                                       // MatchingPursuit.cpp:50-54
+        done = true; count = step;
+    } else {
+        const int prev = ws.prev_id[tc];
+        const unsigned delta = (step > 0) ? (((unsigned)(best_idx - prev) << 1) ^ (unsigned)((best_idx - prev) >> 31))
+                                          : (unsigned)best_idx;
+        ws.prev_id[tc] = best_idx;
+        const double qstep = quant[ch * K + step];
+        const int q = (int)__builtin_round(best_val / qstep);
+        const unsigned zz = ((unsigned)q << 1) ^ (unsigned)(q >> 31);
+        record = (delta & 0xFFFFu) | ((zz & 0xFFFFu) << 16);
+        if (q == 0) {                                         // :66-69
+            done = true; count = step;
+        } else {
+            const double coeff = qstep * (double)q;
+            const double* row = (best_sel < 0) ? (dict.base + (long long)(~best_sel) * N)
+                                               : (dict.detail + ((long long)ch * dict.detail_rows + best_sel) * N);
+            for (int j = 0; j < N; ++j) {
+                const double scaled = coeff * row[j];         // Vector::Scale
+                r[j] = r[j] - scaled;                         // Vector::Subtract
+            }
+            if (best_idx < dict.num_base) {                   // unlock DetailBasis[choice]; duplicates are appended again
+                unsigned e = (unsigned)best_idx;
+                for (int i = 0; i < nb; ++i)
+                    if ((ws.blk_list[(long long)tc * kMaxDeviceK + i] & 0x7FFFu) == (unsigned)best_idx) e |= 0x8000u;
+                ws.blk_list[(long long)tc * kMaxDeviceK + nb] = (uint16_t)e;
+                ws.nblk[tc] = nb + 1;
+                ws.extra_rows[tc] = extra + dict.block_rows[best_idx];
+                unlocked = true;
+            }
+            if (step + 1 == K) { done = true; count = K; }
+        }
+    }
+    out.choices[rec * K + step] = record;
+    if (done) {
+        double e2 = 0.0;
+        for (int j = 0; j < N; ++j) e2 += r[j] * r[j];
+        out.counts[rec] = (uint16_t)count;
+        if (out.energy) out.energy[rec] = e2;
+        if (out.swept) out.swept[rec] = swept;
+    } else {
+        const unsigned slot = atomicAdd(&ws.counters[cur ^ 1], 1u);
+        ws.act[cur ^ 1][slot] = tc;
+        // items of the next step: every unlocked, non-repeated block except block 0
+        unsigned* cnt = ws.bucket_count[(step + 1) & 1];
+        const int nb2 = nb + (unlocked ? 1 : 0);
+        for (int i = 0; i < nb2; ++i) {
+            const unsigned e = ws.blk_list[(long long)tc * kMaxDeviceK + i];
+            if (e == 0 || (e & 0x8000u)) continue;
+            atomicAdd(&cnt[(ch << 9) | (int)e], 1u);
+        }
+    }
+}
+
+// Per-stream symbol histograms for the Huffman/Golomb stage (RCCL all-reduce input):
+// stream 0 = lengths, stream 1 + 2K*ch + 2i (+1) = codes[2K*ch + 2i (+1)] (CompressedImage.cpp:556-572).
+__global__ __launch_bounds__(256) void mp_histogram_kernel(const HistParams p)
+{
+    const long long n = p.tiles * 3;
+    for (long long o = blockIdx.x * (long long)blockDim.x + threadIdx.x; o < n; o += (long long)gridDim.x * blockDim.x) {
+        const int ch = (int)(o % 3);
+        const int cnt = p.counts[o];
+        atomicAdd(&p.hist[cnt & (kHistBins - 1)], 1u);
+        for (int i = 0; i < cnt; ++i) {
+            const uint32_t rec = p.choices[o * p.K + i];
+            const int s = 1 + 2 * p.K * ch + 2 * i;
+            atomicAdd(&p.hist[(long long)s * kHistBins + (rec & 0xFFFFu & (kHistBins - 1))], 1u);
+            atomicAdd(&p.hist[(long long)(s + 1) * kHistBins + ((rec >> 16) & (kHistBins - 1))], 1u);
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
+// host side: workspace carving and the per-step launch sequence
+// --------------------------------------------------------------------------------------------------
+namespace {
+size_t align_up(size_t v) { return (v + 255) & ~static_cast<size_t>(255); }
+
+struct Carver {
+    char* base;
+    size_t off = 0;
+    template <class T>
+    T* take(size_t count) {
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += align_up(count * sizeof(T));
+        return p;
+    }
+};
+
+Workspace carve(char* mem, int cap, int K, size_t* total)
+{
+    Carver c{mem};
+    Workspace w{};
+    const size_t n = static_cast<size_t>(cap);
+    w.cap = cap;
+    w.max_items = static_cast<long long>(n) * (K > 1 ? K - 1 : 1);
+    w.max_chunks = static_cast<int>(w.max_items / kChunkItems) + kNumBuckets + 1;
+    w.r = c.take<double>(n * N);
+    w.part_val = c.take<double>(n * kMaxParts);
+    w.part_idx = c.take<int>(n * kMaxParts);
+    w.prev_id = c.take<int>(n);
+    w.nblk = c.take<int>(n);
+    w.extra_rows = c.take<int>(n);
+    w.swept = c.take<unsigned>(n);
+    w.blk_list = c.take<uint16_t>(n * kMaxDeviceK);
+    w.item_slot = c.take<int>(n * kMaxDeviceK);
+    w.out_index = c.take<int>(n);
+    w.act[0] = c.take<int>(n);
+    w.act[1] = c.take<int>(n);
+    w.counters = c.take<unsigned>(16);
+    w.bucket_count[0] = c.take<unsigned>(kNumBuckets);
+    w.bucket_count[1] = c.take<unsigned>(kNumBuckets);
+    w.bucket_start = c.take<unsigned>(kNumBuckets + 1);
+    w.bucket_cursor = c.take<unsigned>(kNumBuckets);
+    w.chunks = c.take<int>(static_cast<size_t>(w.max_chunks) * 4);
+    w.items = c.take<int>(static_cast<size_t>(w.max_items));
+    w.proj = c.take<double>(static_cast<size_t>(w.max_items) * N);
+    w.proj0 = c.take<double>((n + 64) * N);
+    if (total) *total = c.off;
+    return w;
+}
+}  // namespace
+
+size_t workspace_bytes(int cap, int K)
+{
+    size_t total = 0;
+    carve(nullptr, cap, K, &total);
+    return total;
+}
+
+Workspace carve_workspace(void* device_mem, int cap, int K) { return carve(static_cast<char*>(device_mem), cap, K, nullptr); }
+
+int enqueue_pursuit(const DictDevice& dict, const Workspace& ws, const FrameInput& in, const Outputs& out,
+                    const double* quant_dev, int K, long long tc_begin, int n, int parts, void* stream_)
+{
+    hipStream_t s = static_cast<hipStream_t>(stream_);
+    if (n < 1 || n > ws.cap) return (int)hipErrorInvalidValue;
+    if (parts < 1) parts = 1;
+    if (parts > kMaxParts) parts = kMaxParts;
+    const unsigned groups = (unsigned)((n + 63) / 64);
+    const unsigned blocks256 = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(mp_init_kernel, dim3(blocks256), dim3(256), 0, s, ws, in, tc_begin, n);
+    for (int step = 0; step < K; ++step) {
+        const int cur = step & 1;
+        if (step > 0) {
+            hipLaunchKernelGGL(mp_bucket_kernel, dim3(1), dim3(1024), 0, s, ws, step & 1);
+            hipLaunchKernelGGL(mp_fill_kernel, dim3(blocks256), dim3(256), 0, s, ws, cur);
+        }
+        hipLaunchKernelGGL(mp_base_kernel, dim3(groups * (unsigned)parts), dim3(64), 0, s, ws, dict, cur, parts);
+        if (step > 0) {
+            hipLaunchKernelGGL(mp_detail0_kernel, dim3(groups * 3u), dim3(64), 0, s, ws, dict, cur);
+            unsigned dwaves = groups * 2u;
+            if (dwaves > 6144u) dwaves = 6144u;
+            if (dwaves < 64u) dwaves = 64u;
+            hipLaunchKernelGGL(mp_detail_kernel, dim3(dwaves), dim3(64), 0, s, ws, dict);
+        }
+        hipLaunchKernelGGL(mp_finish_kernel, dim3(blocks256), dim3(256), 0, s, ws, dict, out, quant_dev, K, step, cur,
+                           parts);
+    }
+    return (int)hipGetLastError();
+}
+
+int launch_histogram(const HistParams& p, void* stream)
+{
+    long long n = p.tiles * 3;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(mp_histogram_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+    return (int)hipGetLastError();
+}
+
+}  // namespace mpc

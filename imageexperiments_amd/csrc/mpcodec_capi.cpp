@@ -54,12 +54,76 @@ struct mpc_context {
     double* d_quant = nullptr;
     int32_t* d_rows = nullptr;
     int32_t* d_rowoff = nullptr;
-    unsigned* d_queue = nullptr;
-    unsigned long long* d_phase = nullptr;   // diagnostics: per-phase shader clocks (mpc_debug_*)
-    bool phase_enabled = false;
+    void* d_workspace = nullptr;      // step-synchronous pursuit state for up to ws_cap tile-channels
+    size_t ws_bytes = 0;
+    int ws_cap = 0;
+    mpc::Workspace ws{};
     int base_rows_padded = 0;
     int max_waves = 0;
+    int num_cus = 0;
 };
+
+namespace {
+constexpr long long kMaxBatch = 3LL * 262144;       // tile-channels per pursuit batch (workspace is sized for it)
+
+mpc::DictDevice dict_device(const mpc_context* c) {
+    mpc::DictDevice d{};
+    d.base = c->d_base;
+    d.num_base = c->dict.num_base;
+    d.base_rows_padded = c->base_rows_padded;
+    d.detail = c->d_detail;
+    d.detail_t = c->d_detail_t;
+    d.detail_rows = c->dict.total_detail_rows();
+    d.block_rows = c->d_rows;
+    d.block_row_off = c->d_rowoff;
+    return d;
+}
+
+// grow-only workspace; allocation synchronises the device, so callers that must not (graph capture)
+// call mpc_reserve() first
+mpc_status ensure_workspace(mpc_context* c, long long tile_channels) {
+    long long cap = tile_channels < kMaxBatch ? tile_channels : kMaxBatch;
+    cap = (cap + 255) / 256 * 256;
+    if (cap <= c->ws_cap) return MPC_OK;
+    if (c->d_workspace) {
+        if (hipDeviceSynchronize() != hipSuccess) return fail(MPC_ERR_HIP, "device synchronise failed");
+        (void)hipFree(c->d_workspace);
+        c->d_workspace = nullptr;
+        c->ws_cap = 0;
+    }
+    const size_t bytes = mpc::workspace_bytes(static_cast<int>(cap), c->K);
+    hipError_t e = hipMalloc(&c->d_workspace, bytes);
+    if (e != hipSuccess) return fail(MPC_ERR_ALLOC, "workspace of %zu bytes: %s", bytes, hipGetErrorString(e));
+    c->ws_bytes = bytes;
+    c->ws_cap = static_cast<int>(cap);
+    c->ws = mpc::carve_workspace(c->d_workspace, c->ws_cap, c->K);
+    return MPC_OK;
+}
+
+// split the base sweep so that a step fills the machine ~3 waves per SIMD deep even for small batches
+int pick_parts(const mpc_context* c, long long n) {
+    const long long groups = (n + 63) / 64;
+    const long long want = 12LL * (c->num_cus > 0 ? c->num_cus : 256);
+    long long parts = (want + groups - 1) / groups;
+    if (parts < 1) parts = 1;
+    if (parts > mpc::kMaxParts) parts = mpc::kMaxParts;
+    return static_cast<int>(parts);
+}
+
+mpc_status run_pursuit(mpc_context* c, const mpc::FrameInput& in, const mpc::Outputs& out, const double* d_quant,
+                       long long total_tc, void* stream) {
+    mpc_status st = ensure_workspace(c, total_tc);
+    if (st != MPC_OK) return st;
+    const mpc::DictDevice dict = dict_device(c);
+    for (long long begin = 0; begin < total_tc; begin += c->ws_cap) {
+        const long long n = (total_tc - begin < c->ws_cap) ? total_tc - begin : c->ws_cap;
+        const int err = mpc::enqueue_pursuit(dict, c->ws, in, out, d_quant, c->K, begin, static_cast<int>(n),
+                                             pick_parts(c, n), stream);
+        if (err != 0) return fail(MPC_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(err)));
+    }
+    return MPC_OK;
+}
+}  // namespace
 
 extern "C" {
 
@@ -107,14 +171,13 @@ mpc_status mpc_context_create(int K, int block_size, double bpp, int device, mpc
         if (e == hipSuccess) e = upload(&c->d_quant, c->quant.data(), c->quant.size());
         if (e == hipSuccess) e = upload(&c->d_rows, c->dict.block_rows.data(), c->dict.block_rows.size());
         if (e == hipSuccess) e = upload(&c->d_rowoff, c->dict.block_row_off.data(), c->dict.block_row_off.size());
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_queue), 64 * sizeof(unsigned));
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_phase), 8 * sizeof(unsigned long long));
-        if (e == hipSuccess) e = hipMemset(c->d_phase, 0, 8 * sizeof(unsigned long long));
+
         if (e != hipSuccess) {
             mpc_context_destroy(c);
             return fail(MPC_ERR_HIP, "device setup failed: %s", hipGetErrorString(e));
         }
-        c->max_waves = mpc::encode_max_resident_waves();
+        (void)hipDeviceGetAttribute(&c->num_cus, hipDeviceAttributeMultiprocessorCount, device);
+        c->max_waves = 12 * c->num_cus;
     }
     *out = c;
     return MPC_OK;
@@ -130,8 +193,7 @@ void mpc_context_destroy(mpc_context* c) {
         (void)hipFree(c->d_quant);
         (void)hipFree(c->d_rows);
         (void)hipFree(c->d_rowoff);
-        (void)hipFree(c->d_queue);
-        (void)hipFree(c->d_phase);
+        (void)hipFree(c->d_workspace);
     }
     delete c;
 }
@@ -170,23 +232,6 @@ mpc_status mpc_context_get_dictionary(const mpc_context* c, double* base, int32_
     return MPC_OK;
 }
 
-static int pick_waves(const mpc_context* c, long long tasks, int requested) {
-    if (requested > 0) return requested;
-    long long need = (tasks + 63) / 64;
-    long long w = c->max_waves > 0 ? c->max_waves : 1024;
-    if (need < w) w = need;
-    return static_cast<int>(w < 1 ? 1 : w);
-}
-
-// lanes per wave that prefer the luma queue: enough for every Y pursuit to start in the first iteration,
-// spread evenly over the waves; all 64 when there are more Y tasks than lanes (pure longest-job-first).
-static int pick_y_lanes(long long y_tasks, int waves) {
-    long long per_wave = (y_tasks + waves - 1) / waves;
-    if (per_wave > 64) per_wave = 64;
-    if (per_wave < 1) per_wave = 1;
-    return static_cast<int>(per_wave);
-}
-
 mpc_status mpc_encode_batch_device(mpc_context* c, const uint8_t* d_rgb, int frames, size_t frame_stride, int width,
                                    int height, size_t row_stride, int tile_row_begin, int tile_row_end,
                                    const double* quant, uint16_t* d_counts, mpc_basis_choice* d_choices,
@@ -204,41 +249,28 @@ mpc_status mpc_encode_batch_device(mpc_context* c, const uint8_t* d_rgb, int fra
     const long long tiles = static_cast<long long>(tiles_x) * (tile_row_end - tile_row_begin) * frames;
     if (tiles * 3 >= (1LL << 31)) return fail(MPC_ERR_ARGUMENT, "batch too large");
     hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipSetDevice(c->device));
     if (quant) HIP_TRY(hipMemcpyAsync(c->d_quant, quant, 3 * sizeof(double) * c->K, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemsetAsync(c->d_queue, 0, 2 * sizeof(unsigned), s));
     HIP_TRY(hipMemsetAsync(d_choices, 0, sizeof(mpc_basis_choice) * tiles * 3 * c->K, s));
-    mpc::EncodeParams p{};
-    p.rgb = d_rgb;
-    p.width = width;
-    p.height = height;
-    p.row_stride = static_cast<long long>(row_stride);
-    p.frames = frames;
-    p.frame_stride = static_cast<long long>(frame_stride);
-    p.tile_row_begin = tile_row_begin;
-    p.tile_rows = tile_row_end - tile_row_begin;
-    p.tiles_x = tiles_x;
-    p.K = c->K;
-    p.base = c->d_base;
-    p.num_base = c->dict.num_base;
-    p.base_rows_padded = c->base_rows_padded;
-    p.detail = c->d_detail;
-    p.detail_t = c->d_detail_t;
-    p.detail_rows = c->dict.total_detail_rows();
-    p.block_rows = c->d_rows;
-    p.block_row_off = c->d_rowoff;
-    p.quant = c->d_quant;
-    p.counts = d_counts;
-    p.choices = reinterpret_cast<uint32_t*>(d_choices);
-    p.energy = d_energy;
-    p.swept = d_swept;
-    p.queue = c->d_queue;
-    p.vec_in = nullptr;
-    const int nwaves = pick_waves(c, tiles * 3, waves);
-    p.y_lanes = pick_y_lanes(tiles, nwaves);
-    p.phase_cycles = c->phase_enabled ? c->d_phase : nullptr;
-    const int err = mpc::launch_encode(p, nwaves, stream);
-    if (err != 0) return fail(MPC_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(err)));
-    return MPC_OK;
+    mpc::FrameInput in{};
+    in.rgb = d_rgb;
+    in.width = width;
+    in.height = height;
+    in.row_stride = static_cast<long long>(row_stride);
+    in.frames = frames;
+    in.frame_stride = static_cast<long long>(frame_stride);
+    in.tile_row_begin = tile_row_begin;
+    in.tile_rows = tile_row_end - tile_row_begin;
+    in.tiles_x = tiles_x;
+    in.vec_in = nullptr;
+    in.vec_channel = 0;
+    mpc::Outputs out{};
+    out.counts = d_counts;
+    out.choices = reinterpret_cast<uint32_t*>(d_choices);
+    out.energy = d_energy;
+    out.swept = d_swept;
+    (void)waves;
+    return run_pursuit(c, in, out, c->d_quant, tiles * 3, stream);
 }
 
 mpc_status mpc_encode_tiles_device(mpc_context* c, const uint8_t* d_rgb, int width, int height, size_t row_stride,
@@ -335,38 +367,24 @@ mpc_status mpc_calc_mp_batch(mpc_context* c, int channel, const double* quant_k,
     if (e == hipSuccess) e = hipMemcpy(d_in, inputs, sizeof(double) * 64 * count, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d_q, q.data(), sizeof(double) * 3 * K, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(d_choices, 0, sizeof(uint32_t) * count * K);
-    if (e == hipSuccess) e = hipMemset(c->d_queue, 0, 2 * sizeof(unsigned));
-    int err = 0;
+    mpc_status st = MPC_OK;
     if (e == hipSuccess) {
-        mpc::EncodeParams p{};
-        p.K = K;
-        p.base = c->d_base;
-        p.num_base = c->dict.num_base;
-        p.base_rows_padded = c->base_rows_padded;
-        p.detail = c->d_detail;
-        p.detail_t = c->d_detail_t;
-        p.detail_rows = c->dict.total_detail_rows();
-        p.block_rows = c->d_rows;
-        p.block_row_off = c->d_rowoff;
-        p.quant = d_q;
-        p.counts = d_counts;
-        p.choices = d_choices;
-        p.energy = d_energy;
-        p.swept = d_swept;
-        p.queue = c->d_queue;
-        p.frames = 1;
-        p.vec_in = d_in;
-        p.vec_count = count;
-        p.vec_channel = channel;
-        p.y_lanes = 64;
-        p.phase_cycles = nullptr;
-        err = mpc::launch_encode(p, pick_waves(c, count, 0), nullptr);
-        if (err == 0) e = hipDeviceSynchronize();
-        if (err == 0 && e == hipSuccess) e = hipMemcpy(counts, d_counts, sizeof(uint16_t) * count, hipMemcpyDeviceToHost);
-        if (err == 0 && e == hipSuccess)
+        mpc::FrameInput in{};
+        in.vec_in = d_in;
+        in.vec_channel = channel;
+        in.frames = 1;
+        mpc::Outputs out{};
+        out.counts = d_counts;
+        out.choices = d_choices;
+        out.energy = d_energy;
+        out.swept = d_swept;
+        st = run_pursuit(c, in, out, d_q, count, nullptr);
+        if (st == MPC_OK) e = hipDeviceSynchronize();
+        if (st == MPC_OK && e == hipSuccess) e = hipMemcpy(counts, d_counts, sizeof(uint16_t) * count, hipMemcpyDeviceToHost);
+        if (st == MPC_OK && e == hipSuccess)
             e = hipMemcpy(choices, d_choices, sizeof(uint32_t) * count * K, hipMemcpyDeviceToHost);
-        if (err == 0 && e == hipSuccess && energy) e = hipMemcpy(energy, d_energy, sizeof(double) * count, hipMemcpyDeviceToHost);
-        if (err == 0 && e == hipSuccess && swept) e = hipMemcpy(swept, d_swept, sizeof(uint32_t) * count, hipMemcpyDeviceToHost);
+        if (st == MPC_OK && e == hipSuccess && energy) e = hipMemcpy(energy, d_energy, sizeof(double) * count, hipMemcpyDeviceToHost);
+        if (st == MPC_OK && e == hipSuccess && swept) e = hipMemcpy(swept, d_swept, sizeof(uint32_t) * count, hipMemcpyDeviceToHost);
     }
     (void)hipFree(d_in);
     (void)hipFree(d_counts);
@@ -374,23 +392,16 @@ mpc_status mpc_calc_mp_batch(mpc_context* c, int channel, const double* quant_k,
     (void)hipFree(d_energy);
     (void)hipFree(d_swept);
     (void)hipFree(d_q);
-    if (err != 0) return fail(MPC_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(err)));
+    if (st != MPC_OK) return st;
     if (e != hipSuccess) return fail(MPC_ERR_HIP, "HIP failure: %s", hipGetErrorString(e));
     return MPC_OK;
 }
 
-void mpc_debug_enable_phases(mpc_context* c, int on) {
-    if (c) c->phase_enabled = on != 0;
-}
-
-mpc_status mpc_debug_read_phases(mpc_context* c, unsigned long long out[5], int reset) {
-    if (!c || !out) return fail(MPC_ERR_ARGUMENT, "null argument");
+mpc_status mpc_reserve(mpc_context* c, long long max_tiles) {
+    if (!c || max_tiles < 1) return fail(MPC_ERR_ARGUMENT, "bad argument");
     if (c->device < 0) return fail(MPC_ERR_NO_DEVICE, "context was created without a device");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out, c->d_phase, 5 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    if (reset) HIP_TRY(hipMemset(c->d_phase, 0, 8 * sizeof(unsigned long long)));
-    return MPC_OK;
+    return ensure_workspace(c, max_tiles * 3);
 }
 
 mpc_status mpc_calc_mp(mpc_context* c, int channel, const double* quant_k, const double* input64,

@@ -97,8 +97,8 @@ mpc_status mpc_context_get_dictionary(const mpc_context* ctx, double* base, int3
  *   d_energy [tiles][3]      f64   sum of squares of the final residual (diagnostic, not in CompressionLib)
  *   d_swept  [tiles][3]      u32   dictionary rows correlated, SURVEY 8(d) "S"
  * d_energy / d_swept may be NULL.  quant: host pointer to 3*K doubles or NULL for the context's tables.
- * stream: hipStream_t (NULL = default stream).  Asynchronous; no allocation, no synchronisation.
- * waves: grid size in wave64 workgroups, 0 = automatic. */
+ * stream: hipStream_t (NULL = default stream).  Asynchronous; no synchronisation, and no allocation once the
+ * workspace covers the call (mpc_reserve).  waves: reserved, pass 0. */
 mpc_status mpc_encode_tiles_device(mpc_context* ctx, const uint8_t* d_rgb, int width, int height, size_t row_stride,
                                    int tile_row_begin, int tile_row_end, const double* quant,
                                    uint16_t* d_counts, mpc_basis_choice* d_choices, double* d_energy, uint32_t* d_swept,
@@ -132,12 +132,10 @@ mpc_status mpc_calc_mp(mpc_context* ctx, int channel, const double* quant_k, con
 mpc_status mpc_calc_mp_batch(mpc_context* ctx, int channel, const double* quant_k, const double* inputs, int count,
                              mpc_basis_choice* choices, uint16_t* counts, double* energy, uint32_t* swept);
 
-/* ---- diagnostics (profiling builds of a run; never changes results) ----------------------------------
- * When enabled, every wave of the encode kernel adds its shader-clock time per phase to a context-owned
- * buffer: out[0] refill, out[1] base sweep, out[2] detail sweep, out[3] quantise/update, out[4] = wave
- * iterations.  mpc_debug_read_phases synchronises the device. */
-void mpc_debug_enable_phases(mpc_context* ctx, int on);
-mpc_status mpc_debug_read_phases(mpc_context* ctx, unsigned long long out[5], int reset);
+/* Pre-allocates the device workspace for calls of up to max_tiles tiles (3 tile-channels each).  The encode
+ * entry points grow the workspace on demand, which synchronises the device; callers that must not synchronise
+ * (stream capture) reserve first.  Larger inputs are processed in batches of 262144 tiles. */
+mpc_status mpc_reserve(mpc_context* ctx, long long max_tiles);
 
 #ifdef __cplusplus
 }
