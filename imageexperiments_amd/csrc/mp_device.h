@@ -9,16 +9,17 @@
 //     bucket   (s>0) prefix-sum the per-block item counts, emit chunk descriptors
 //     fill     (s>0) scatter (tile-channel, block) items into their block's bucket
 //     base     correlate r with the 510 shared base atoms                          (Select, MatchingPursuit.cpp:7-25)
-//     detail0  (s>0) correlate r with DetailBasis[0] (the DC block nearly every tile unlocks first)
-//     detail   (s>0) correlate r with every other unlocked detail block, bucketed by block
+//     detail0  (s>0) correlate r with DetailBasis[0] (the DC block nearly every tile unlocks first; no bucketing)
+//     detail   (s>0) correlate r with every other unlocked detail block, bucketed by (channel, block)
 //     finish   argmax in dictionary order, quantise, record, residual update, unlock block, compact
 //                                                                                   (MatchingPursuit.cpp:55-71)
-// Why this shape: the base atoms are common to all tile-channels, so `base` keeps 64 residuals in the VGPRs of
-// a wave (lane = tile-channel) and streams the atoms as wave-uniform scalars; the detail blocks differ per
-// tile-channel, so `detail` does the opposite -- a wave keeps one block's 62/63 atom rows in VGPRs (lane =
-// atom row) and streams the residuals of all tile-channels that unlocked that block as wave-uniform scalars.
-// Either way each multiply-add takes one s_load'ed double and one VGPR double: no LDS or L2 traffic per MAC,
-// and every dot product stays the reference's sequential tot += l*r.
+// Why this shape: every sweep is the same loop -- 64 tile-channels per wave (lane = tile-channel, its residual
+// in 128 VGPRs) against a run of dictionary rows that is wave-uniform and arrives through the scalar cache as
+// SGPR operands of v_mul_f64: one s_load'ed double and one VGPR double per multiply-add, no LDS or vector-memory
+// traffic per MAC, dot products in the reference's sequential order, argmax in-register in index order.
+// The base rows are common to all tile-channels; detail blocks differ per tile-channel, so the (tile-channel,
+// block) pairs of a step are bucketed by block and a wave takes up to 64 tile-channels of ONE bucket.
+// Active tile-channels are kept in per-channel lists (the detail rows are per channel).
 #pragma once
 #include <cstddef>
 #include <cstdint>
@@ -35,8 +36,7 @@ struct DictDevice {
     const double* base;              // [base_rows_padded + 1][64] row-major, zero rows after num_base
     int num_base;                    // 510
     int base_rows_padded;
-    const double* detail;            // [3][detail_rows][64] row-major
-    const double* detail_t;          // [3][num_base][32][64][2] transposed + padded blocks
+    const double* detail;            // [3][detail_rows][64] row-major (+1 zero row at the very end)
     long long detail_rows;           // rows per channel (31 622)
     const int32_t* block_rows;       // [num_base]
     const int32_t* block_row_off;    // [num_base+1]
@@ -48,22 +48,24 @@ struct Workspace {
     double* r;                       // [cap][64] residuals
     double* part_val;                // [cap][kMaxParts] best projection of each base atom range
     int* part_idx;                   // [cap][kMaxParts]
+    double* cand0_val;               // [cap] best projection on DetailBasis[0] (if unlocked)
+    int* cand0_row;                  // [cap]
     int* prev_id;                    // [cap]
     int* nblk;                       // [cap] entries in blk_list
     int* extra_rows;                 // [cap] rows appended after the base part (duplicates included)
     unsigned* swept;                 // [cap]
     uint16_t* blk_list;              // [cap][32] chosen base atoms in order, bit 15 = repeat of an earlier entry
     int* item_slot;                  // [cap][32] bucket slot of each blk_list entry for the current step
-    int* out_index;                  // [cap] record index (unit*3 + channel) in the caller's outputs
-    int* act[2];                     // [cap] active tile-channel lists (ping-pong)
-    unsigned* counters;              // [16]: 0,1 = n_act ping-pong; 2 = chunk cursor; 3 = n_chunks; 4 = n_items
+    int* out_index;                  // [cap] record index in the low 30 bits, channel in the top 2
+    int* act[2][3];                  // [cap] active tile-channels per channel (ping-pong)
+    unsigned* counters;              // [16]: [cur*3+ch] = active count; 6 = chunk cursor; 7 = n_chunks; 8 = n_items
     unsigned* bucket_count[2];       // [kNumBuckets] items per (channel, block) for this / the next step
     unsigned* bucket_start;          // [kNumBuckets + 1]
     unsigned* bucket_cursor;         // [kNumBuckets]
     int* chunks;                     // [max_chunks][4] = bucket, begin, end, 0
     int* items;                      // [max_items] tile-channel of each item
-    double* proj;                    // [max_items][64] projections of the item's block rows
-    double* proj0;                   // [cap][64] projections on DetailBasis[0], indexed by position in act list
+    double* cand_val;                // [max_items] best projection of the item's block
+    int* cand_row;                   // [max_items]
     long long max_items;
     int max_chunks;
 };

@@ -3,10 +3,11 @@
 // separately rounded mul/add (-ffp-contract=off): integer outputs must equal the reference's
 // double path (MatchingPursuit.cpp:39-74) bit for bit.
 //
-// The two sweep kernels share one inner loop shape: a 64-term sequential dot product
-//     tot = 0; tot += a[j] * b[j]   (j ascending, mathmatrix.cpp:436-444)
-// where one operand lives in 128 VGPRs for the whole loop and the other is wave-uniform and arrives
-// through the scalar data cache (s_load_dwordx16 -> SGPR operand of v_mul_f64).  SMEM returns out of
+// All three sweep kernels share one loop: a 64-term sequential dot product
+//     tot = 0; tot += row[j] * r[j]   (j ascending, mathmatrix.cpp:436-444)
+// per dictionary row, where r (one tile-channel per lane) lives in 128 VGPRs for the whole loop and the
+// row is wave-uniform and arrives through the scalar data cache (s_load_dwordx16 -> SGPR operand of
+// v_mul_f64).  SMEM returns out of
 // order, so the only usable wait is lgkmcnt(0): the loop keeps exactly ONE 16-double group load in
 // flight, issued right after the wait for the previous group, and relies on 2-3 co-resident waves per
 // SIMD to cover what 15 multiply-adds do not (measured: tools/ubench_scalar_sweep.hip).
@@ -60,21 +61,26 @@ __global__ __launch_bounds__(256) void mp_init_kernel(const Workspace ws, const 
             ws.bucket_count[1][b] = 0;
         }
         if (threadIdx.x == 0) {
-            ws.counters[0] = (unsigned)n;
-            ws.counters[1] = 0;
+            const bool vec = in.vec_in != nullptr;
+            for (int c = 0; c < 3; ++c) {
+                ws.counters[c] = vec ? (c == in.vec_channel ? (unsigned)n : 0u) : (unsigned)(n / 3);
+                ws.counters[3 + c] = 0;
+            }
         }
     }
     if (tc >= n) return;
     const long long gtc = tc_begin + tc;
     double* r = ws.r + (long long)tc * N;
-    int ch;
+    int ch, list_pos;
     if (in.vec_in) {
         ch = in.vec_channel;
+        list_pos = tc;
         const double* v = in.vec_in + gtc * N;
         for (int j = 0; j < N; ++j) r[j] = v[j];
     } else {
         const long long unit = gtc / 3;
         ch = (int)(gtc - unit * 3);
+        list_pos = tc / 3;                                   // batches start on a unit boundary
         const int tiles_per_frame = in.tiles_x * in.tile_rows;
         const int frame = (int)(unit / tiles_per_frame);
         const int tile = (int)(unit - (long long)frame * tiles_per_frame);
@@ -102,157 +108,142 @@ __global__ __launch_bounds__(256) void mp_init_kernel(const Workspace ws, const 
     ws.extra_rows[tc] = 0;
     ws.swept[tc] = 0;
     ws.out_index[tc] = (int)((unsigned)gtc | ((unsigned)ch << 30));    // record index in the low 30 bits, channel on top
-    ws.act[0][tc] = tc;
+    ws.act[0][ch][list_pos] = tc;
 }
 
 // --------------------------------------------------------------------------------------------------
-// base sweep: one wave = 64 active tile-channels (lane = tile-channel, residual in 128 VGPRs) x one
-// range of base atoms (wave-uniform, scalar-fed).  Writes the best projection of the range; ranges are
-// combined in index order by the finish kernel.
-// --------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64, 3) void mp_base_kernel(const Workspace ws, const DictDevice dict, int cur, int parts)
-{
-    const int lane = threadIdx.x;
-    const int group = blockIdx.x / parts;
-    const int part = blockIdx.x - group * parts;
-    if (blockIdx.x == 0 && lane == 0) ws.counters[cur ^ 1] = 0;          // next step's active count
-    const int n_act = (int)((scalar_u32_ptr)(uintptr_t)ws.counters)[cur];
-    if (group * 64 >= n_act) return;
-    const int pos = group * 64 + lane;
-    const bool valid = pos < n_act;
-    const int tc = ws.act[cur][valid ? pos : group * 64];
-
-    double r[N];
-    {
-        const double2* src = (const double2*)(ws.r + (long long)tc * N);
-#pragma unroll
-        for (int jj = 0; jj < N / 2; ++jj) {
-            const double2 v = src[jj];
-            r[2 * jj] = v.x;
-            r[2 * jj + 1] = v.y;
-        }
-    }
-    const int per = (dict.base_rows_padded + parts - 1) / parts;
-    const int a0 = part * per;
-    const int a1 = (a0 + per < dict.base_rows_padded) ? a0 + per : dict.base_rows_padded;
-
-    double best_val = 0.0;      // Select(): bestCoeff = 0.0, index = -1 (MatchingPursuit.cpp:9-10)
-    int best_idx = -1;
-    scalar_f64_ptr atom = as_scalar(dict.base) + (long long)a0 * N;
-    double ga[16], gb[16];
-    load_group(ga, atom);
-    for (int a = a0; a < a1; ++a, atom += N) {
-        double tot = 0.0;
-        MAC_GROUP(ga, gb, r, 0, atom + 16)
-        MAC_GROUP(gb, ga, r, 16, atom + 32)
-        MAC_GROUP(ga, gb, r, 32, atom + 48)
-        MAC_GROUP(gb, ga, r, 48, atom + 64)          // row after the last is a zero pad: stays in bounds
-        if (__builtin_fabs(tot) > __builtin_fabs(best_val)) { best_val = tot; best_idx = a; }
-    }
-    if (valid) {
-        ws.part_val[(long long)tc * kMaxParts + part] = best_val;
-        ws.part_idx[(long long)tc * kMaxParts + part] = best_idx;
-    }
-}
-
-// --------------------------------------------------------------------------------------------------
-// detail sweeps: one wave keeps the 62/63 rows of ONE detail block in VGPRs (lane = atom row, rows >=
-// block_rows are zero) and streams tile-channel residuals as scalars.  All 64 projections of an item
-// are stored; the finish kernel scans them in dictionary order.
+// The sweep: `nrows` consecutive dictionary rows (wave-uniform, scalar-fed, one 16-double group load in
+// flight) against the 64 residuals held by the wave.  In-register argmax in row order with the reference's
+// strict '>' (first maximum wins; Select(): bestCoeff = 0.0, index = -1, MatchingPursuit.cpp:9-19).
+// The row after the last one must be readable (zero pads at the end of `base` and `detail`).
 // --------------------------------------------------------------------------------------------------
 namespace {
 
-__device__ __forceinline__ void load_block_rows(double (&row)[N], const double* detail_t, long long block, int lane)
+__device__ __forceinline__ void load_residual(double (&r)[N], const double* src_row)
 {
-    const double2* src = (const double2*)detail_t + block * (N / 2) * 64 + lane;
+    const double2* src = (const double2*)src_row;
 #pragma unroll
     for (int jj = 0; jj < N / 2; ++jj) {
-        const double2 v = src[jj * 64];
-        row[2 * jj] = v.x;
-        row[2 * jj + 1] = v.y;
+        const double2 v = src[jj];
+        r[2 * jj] = v.x;
+        r[2 * jj + 1] = v.y;
     }
 }
 
-// items: bit mask `todo` over 64 candidate slots; tc of slot p is lane p's `tc_lane`; results to dst + p*64
-__device__ __forceinline__ void sweep_items(const double (&row)[N], unsigned long long todo, int tc_lane,
-                                            const double* r_all, double* dst, int lane)
+__device__ __forceinline__ void sweep_rows(const double (&r)[N], scalar_f64_ptr rows, int nrows, double& best_val,
+                                           int& best_row)
 {
-    if (!todo) return;
-    int p = __builtin_ctzll(todo);
-    todo &= todo - 1;
-    const int tc0 = __builtin_amdgcn_readlane(tc_lane, p);
-    scalar_f64_ptr res = as_scalar(r_all) + (long long)tc0 * N;
+    best_val = 0.0;
+    best_row = -1;
     double ga[16], gb[16];
-    load_group(ga, res);
-    for (;;) {
-        // look ahead: the residual of the next item (or this one again, harmlessly, when it is the last)
-        const bool more = todo != 0;
-        const int pn = more ? __builtin_ctzll(todo) : p;
-        const int tcn = __builtin_amdgcn_readlane(tc_lane, pn);
-        scalar_f64_ptr resn = as_scalar(r_all) + (long long)tcn * N;
+    load_group(ga, rows);
+    for (int a = 0; a < nrows; ++a, rows += N) {
         double tot = 0.0;
-        MAC_GROUP(ga, gb, row, 0, res + 16)
-        MAC_GROUP(gb, ga, row, 16, res + 32)
-        MAC_GROUP(ga, gb, row, 32, res + 48)
-        MAC_GROUP(gb, ga, row, 48, resn)
-        dst[(long long)p * N + lane] = tot;
-        if (!more) break;
-        todo &= todo - 1;
-        p = pn;
-        res = resn;
+        MAC_GROUP(ga, gb, r, 0, rows + 16)
+        MAC_GROUP(gb, ga, r, 16, rows + 32)
+        MAC_GROUP(ga, gb, r, 32, rows + 48)
+        MAC_GROUP(gb, ga, r, 48, rows + 64)
+        if (__builtin_fabs(tot) > __builtin_fabs(best_val)) { best_val = tot; best_row = a; }
     }
+}
+
+__device__ __forceinline__ unsigned scalar_counter(const unsigned* counters, int i)
+{
+    return ((scalar_u32_ptr)(uintptr_t)counters)[i];
 }
 
 }  // namespace
 
-// DetailBasis[0] (unlocked by the DC atom, i.e. by nearly every tile-channel at step 0): no bucketing, the
-// wave walks 64 consecutive entries of the active list and takes those of its channel that hold block 0.
-__global__ __launch_bounds__(64, 3) void mp_detail0_kernel(const Workspace ws, const DictDevice dict, int cur)
+// base sweep: grid = 3 channels x groups x parts.  One wave = 64 entries of one channel's active list x one
+// range of the 510 base atoms; the ranges are combined in index order by the finish kernel.
+__global__ __launch_bounds__(64, 3) void mp_base_kernel(const Workspace ws, const DictDevice dict, int cur, int groups,
+                                                        int parts)
 {
     const int lane = threadIdx.x;
-    const int group = blockIdx.x / 3;
-    const int ch = blockIdx.x - group * 3;
-    const int n_act = (int)((scalar_u32_ptr)(uintptr_t)ws.counters)[cur];
+    const int ch = blockIdx.x / (groups * parts);
+    const int rem = blockIdx.x - ch * groups * parts;
+    const int group = rem / parts;
+    const int part = rem - group * parts;
+    if (blockIdx.x == 0 && lane < 3) ws.counters[(cur ^ 1) * 3 + lane] = 0;      // next step's active counts
+    const int n_act = (int)scalar_counter(ws.counters, cur * 3 + ch);
     if (group * 64 >= n_act) return;
     const int pos = group * 64 + lane;
-    int tc = 0;
-    bool mine = false;
-    if (pos < n_act) {
-        tc = ws.act[cur][pos];
-        const int nb = ws.nblk[tc];
-        if (((unsigned)ws.out_index[tc] >> 30) == (unsigned)ch) {
-            for (int i = 0; i < nb; ++i)
-                if (ws.blk_list[(long long)tc * kMaxDeviceK + i] == 0) mine = true;     // first occurrence of block 0
-        }
+    const bool valid = pos < n_act;
+    const int tc = ws.act[cur][ch][valid ? pos : group * 64];
+    double r[N];
+    load_residual(r, ws.r + (long long)tc * N);
+    const int per = (dict.base_rows_padded + parts - 1) / parts;
+    const int a0 = part * per;
+    const int a1 = (a0 + per < dict.base_rows_padded) ? a0 + per : dict.base_rows_padded;
+    double best_val;
+    int best_row;
+    sweep_rows(r, as_scalar(dict.base) + (long long)a0 * N, a1 - a0, best_val, best_row);
+    if (valid) {
+        ws.part_val[(long long)tc * kMaxParts + part] = best_val;
+        ws.part_idx[(long long)tc * kMaxParts + part] = (best_row < 0) ? -1 : a0 + best_row;
     }
-    const unsigned long long todo = __ballot(mine);
-    if (!todo) return;
-    double row[N];
-    load_block_rows(row, dict.detail_t, (long long)ch * dict.num_base + 0, lane);
-    sweep_items(row, todo, tc, ws.r, ws.proj0 + (long long)group * 64 * N, lane);
 }
 
-// every other block: chunks of <= 64 items of one (channel, block) bucket, pulled from a device-side cursor
+// DetailBasis[0] (unlocked by the DC atom, i.e. by nearly every tile-channel at step 0): no bucketing -- the
+// wave takes 64 consecutive entries of its channel's active list; lanes that have not unlocked block 0 idle.
+__global__ __launch_bounds__(64, 3) void mp_detail0_kernel(const Workspace ws, const DictDevice dict, int cur, int groups)
+{
+    const int lane = threadIdx.x;
+    const int ch = blockIdx.x / groups;
+    const int group = blockIdx.x - ch * groups;
+    const int n_act = (int)scalar_counter(ws.counters, cur * 3 + ch);
+    if (group * 64 >= n_act) return;
+    const int pos = group * 64 + lane;
+    const bool valid = pos < n_act;
+    const int tc = ws.act[cur][ch][valid ? pos : group * 64];
+    bool has0 = false;
+    if (valid) {
+        const int nb = ws.nblk[tc];
+        for (int i = 0; i < nb; ++i)
+            if (ws.blk_list[(long long)tc * kMaxDeviceK + i] == 0) has0 = true;         // first occurrence of block 0
+    }
+    if (!__ballot(has0)) return;
+    double r[N];
+    load_residual(r, ws.r + (long long)tc * N);
+    double best_val;
+    int best_row;
+    sweep_rows(r, as_scalar(dict.detail) + (long long)ch * dict.detail_rows * N, dict.block_rows[0], best_val, best_row);
+    if (has0) {
+        ws.cand0_val[tc] = best_val;
+        ws.cand0_row[tc] = best_row;
+    }
+}
+
+// every other block: chunks of <= 64 items (tile-channels) of one (channel, block) bucket, pulled from a
+// device-side cursor; lane = item.
 __global__ __launch_bounds__(64, 3) void mp_detail_kernel(const Workspace ws, const DictDevice dict)
 {
     const int lane = threadIdx.x;
-    const unsigned n_chunks = ((scalar_u32_ptr)(uintptr_t)ws.counters)[3];
+    const unsigned n_chunks = scalar_counter(ws.counters, 7);
     for (;;) {
         unsigned c = 0;
-        if (lane == 0) c = atomicAdd(&ws.counters[2], 1u);
+        if (lane == 0) c = atomicAdd(&ws.counters[6], 1u);
         c = (unsigned)__builtin_amdgcn_readfirstlane((int)c);
         if (c >= n_chunks) break;
-        const int bucket = ws.chunks[4 * (long long)c + 0];
-        const int begin = ws.chunks[4 * (long long)c + 1];
-        const int end = ws.chunks[4 * (long long)c + 2];
+        const int* desc = ws.chunks + 4 * (long long)c;
+        const int bucket = __builtin_amdgcn_readfirstlane(desc[0]);
+        const int begin = __builtin_amdgcn_readfirstlane(desc[1]);
+        const int end = __builtin_amdgcn_readfirstlane(desc[2]);
         const int ch = bucket >> 9, blk = bucket & 511;
         const int cnt = end - begin;
-        int tc = 0;
-        if (lane < cnt) tc = ws.items[begin + lane];
-        double row[N];
-        load_block_rows(row, dict.detail_t, (long long)ch * dict.num_base + blk, lane);
-        const unsigned long long todo = (cnt >= 64) ? ~0ULL : ((1ULL << cnt) - 1ULL);
-        sweep_items(row, todo, tc, ws.r, ws.proj + (long long)begin * N, lane);
+        const bool valid = lane < cnt;
+        const int tc = ws.items[begin + (valid ? lane : 0)];
+        double r[N];
+        load_residual(r, ws.r + (long long)tc * N);
+        const int rows = dict.block_rows[blk];
+        const long long first = (long long)ch * dict.detail_rows + dict.block_row_off[blk];
+        double best_val;
+        int best_row;
+        sweep_rows(r, as_scalar(dict.detail) + first * N, rows, best_val, best_row);
+        if (valid) {
+            ws.cand_val[begin + lane] = best_val;
+            ws.cand_row[begin + lane] = best_row;
+        }
     }
 }
 
@@ -301,21 +292,21 @@ __global__ __launch_bounds__(1024) void mp_bucket_kernel(const Workspace ws, int
     }
     if (t == 0) {
         ws.bucket_start[kNumBuckets] = s_items[kNumBuckets - 1];
-        ws.counters[2] = 0;                                     // chunk cursor
-        ws.counters[3] = s_chunks[kNumBuckets - 1];             // chunks this step
-        ws.counters[4] = s_items[kNumBuckets - 1];              // items this step
+        ws.counters[6] = 0;                                     // chunk cursor
+        ws.counters[7] = s_chunks[kNumBuckets - 1];             // chunks this step
+        ws.counters[8] = s_items[kNumBuckets - 1];              // items this step
     }
 }
 
 // fill: each active tile-channel drops one item per unlocked, non-repeated block (block 0 excepted) into
 // that block's bucket and remembers the slot.
-__global__ __launch_bounds__(256) void mp_fill_kernel(const Workspace ws, int cur)
+__global__ __launch_bounds__(256) void mp_fill_kernel(const Workspace ws, int cur, int blocks_per_channel)
 {
-    const int n_act = (int)ws.counters[cur];
-    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ch = blockIdx.x / blocks_per_channel;
+    const int n_act = (int)ws.counters[cur * 3 + ch];
+    const int pos = (blockIdx.x - ch * blocks_per_channel) * blockDim.x + threadIdx.x;
     if (pos >= n_act) return;
-    const int tc = ws.act[cur][pos];
-    const int ch = (int)((unsigned)ws.out_index[tc] >> 30);
+    const int tc = ws.act[cur][ch][pos];
     const int nb = ws.nblk[tc];
     for (int i = 0; i < nb; ++i) {
         const unsigned e = ws.blk_list[(long long)tc * kMaxDeviceK + i];
@@ -334,14 +325,14 @@ __global__ __launch_bounds__(256) void mp_fill_kernel(const Workspace ws, int cu
 // --------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void mp_finish_kernel(const Workspace ws, const DictDevice dict, const Outputs out,
                                                        const double* __restrict__ quant, int K, int step, int cur,
-                                                       int parts)
+                                                       int parts, int blocks_per_channel)
 {
-    const int n_act = (int)ws.counters[cur];
-    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ch = blockIdx.x / blocks_per_channel;
+    const int n_act = (int)ws.counters[cur * 3 + ch];
+    const int pos = (blockIdx.x - ch * blocks_per_channel) * blockDim.x + threadIdx.x;
     if (pos >= n_act) return;
-    const int tc = ws.act[cur][pos];
+    const int tc = ws.act[cur][ch][pos];
     const unsigned oi = (unsigned)ws.out_index[tc];
-    const int ch = (int)(oi >> 30);
     const long long rec = (long long)(oi & 0x3FFFFFFFu);
     const int nb = ws.nblk[tc];
     const int extra = ws.extra_rows[tc];
@@ -360,13 +351,16 @@ __global__ __launch_bounds__(256) void mp_finish_kernel(const Workspace ws, cons
         const int blk = (int)(e & 0x7FFFu);
         const int rows = dict.block_rows[blk];
         if (!(e & 0x8000u)) {               // a repeated block can never win: identical projections at a higher index
-            const double* pr = (blk == 0) ? (ws.proj0 + (long long)pos * N)
-                                          : (ws.proj + (long long)ws.item_slot[(long long)tc * kMaxDeviceK + i] * N);
-            for (int row = 0; row < rows; ++row) {
-                const double v = pr[row];
-                if (__builtin_fabs(v) > __builtin_fabs(best_val)) {
-                    best_val = v; best_idx = off + row; best_sel = dict.block_row_off[blk] + row;
-                }
+            double v;
+            int row;
+            if (blk == 0) { v = ws.cand0_val[tc]; row = ws.cand0_row[tc]; }
+            else {
+                const int slot = ws.item_slot[(long long)tc * kMaxDeviceK + i];
+                v = ws.cand_val[slot];
+                row = ws.cand_row[slot];
+            }
+            if (row >= 0 && __builtin_fabs(v) > __builtin_fabs(best_val)) {
+                best_val = v; best_idx = off + row; best_sel = dict.block_row_off[blk] + row;
             }
         }
         off += rows;
@@ -420,8 +414,14 @@ __global__ __launch_bounds__(256) void mp_finish_kernel(const Workspace ws, cons
         if (out.energy) out.energy[rec] = e2;
         if (out.swept) out.swept[rec] = swept;
     } else {
-        const unsigned slot = atomicAdd(&ws.counters[cur ^ 1], 1u);
-        ws.act[cur ^ 1][slot] = tc;
+        // wave-aggregated append to the channel's next active list (the wave is channel-pure)
+        const unsigned long long going = __ballot(true);
+        const int leader = __builtin_ctzll(going);
+        unsigned first = 0;
+        if ((int)(threadIdx.x & 63) == leader) first = atomicAdd(&ws.counters[(cur ^ 1) * 3 + ch], (unsigned)__popcll(going));
+        first = (unsigned)__builtin_amdgcn_readlane((int)first, leader);
+        const unsigned slot = first + (unsigned)__popcll(going & ((1ULL << (threadIdx.x & 63)) - 1ULL));
+        ws.act[cur ^ 1][ch][slot] = tc;
         // items of the next step: every unlocked, non-repeated block except block 0
         unsigned* cnt = ws.bucket_count[(step + 1) & 1];
         const int nb2 = nb + (unlocked ? 1 : 0);
@@ -486,8 +486,10 @@ Workspace carve(char* mem, int cap, int K, size_t* total)
     w.blk_list = c.take<uint16_t>(n * kMaxDeviceK);
     w.item_slot = c.take<int>(n * kMaxDeviceK);
     w.out_index = c.take<int>(n);
-    w.act[0] = c.take<int>(n);
-    w.act[1] = c.take<int>(n);
+    for (int a = 0; a < 2; ++a)
+        for (int ch = 0; ch < 3; ++ch) w.act[a][ch] = c.take<int>(n);
+    w.cand0_val = c.take<double>(n);
+    w.cand0_row = c.take<int>(n);
     w.counters = c.take<unsigned>(16);
     w.bucket_count[0] = c.take<unsigned>(kNumBuckets);
     w.bucket_count[1] = c.take<unsigned>(kNumBuckets);
@@ -495,8 +497,8 @@ Workspace carve(char* mem, int cap, int K, size_t* total)
     w.bucket_cursor = c.take<unsigned>(kNumBuckets);
     w.chunks = c.take<int>(static_cast<size_t>(w.max_chunks) * 4);
     w.items = c.take<int>(static_cast<size_t>(w.max_items));
-    w.proj = c.take<double>(static_cast<size_t>(w.max_items) * N);
-    w.proj0 = c.take<double>((n + 64) * N);
+    w.cand_val = c.take<double>(static_cast<size_t>(w.max_items));
+    w.cand_row = c.take<int>(static_cast<size_t>(w.max_items));
     if (total) *total = c.off;
     return w;
 }
@@ -518,25 +520,29 @@ int enqueue_pursuit(const DictDevice& dict, const Workspace& ws, const FrameInpu
     if (n < 1 || n > ws.cap) return (int)hipErrorInvalidValue;
     if (parts < 1) parts = 1;
     if (parts > kMaxParts) parts = kMaxParts;
-    const unsigned groups = (unsigned)((n + 63) / 64);
-    const unsigned blocks256 = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(mp_init_kernel, dim3(blocks256), dim3(256), 0, s, ws, in, tc_begin, n);
+    // per-channel list capacity: n/3 units in tile mode (batches hold whole units), n in vector mode
+    const int per_list = in.vec_in ? n : (n + 2) / 3;
+    const unsigned groups = (unsigned)((per_list + 63) / 64);
+    const unsigned bpc = (unsigned)((per_list + 255) / 256);          // 256-thread blocks per channel
+    const unsigned blocks_n = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(mp_init_kernel, dim3(blocks_n), dim3(256), 0, s, ws, in, tc_begin, n);
     for (int step = 0; step < K; ++step) {
         const int cur = step & 1;
         if (step > 0) {
             hipLaunchKernelGGL(mp_bucket_kernel, dim3(1), dim3(1024), 0, s, ws, step & 1);
-            hipLaunchKernelGGL(mp_fill_kernel, dim3(blocks256), dim3(256), 0, s, ws, cur);
+            hipLaunchKernelGGL(mp_fill_kernel, dim3(3u * bpc), dim3(256), 0, s, ws, cur, (int)bpc);
         }
-        hipLaunchKernelGGL(mp_base_kernel, dim3(groups * (unsigned)parts), dim3(64), 0, s, ws, dict, cur, parts);
+        hipLaunchKernelGGL(mp_base_kernel, dim3(3u * groups * (unsigned)parts), dim3(64), 0, s, ws, dict, cur, (int)groups,
+                           parts);
         if (step > 0) {
-            hipLaunchKernelGGL(mp_detail0_kernel, dim3(groups * 3u), dim3(64), 0, s, ws, dict, cur);
-            unsigned dwaves = groups * 2u;
+            hipLaunchKernelGGL(mp_detail0_kernel, dim3(3u * groups), dim3(64), 0, s, ws, dict, cur, (int)groups);
+            unsigned dwaves = 3u * groups;
             if (dwaves > 6144u) dwaves = 6144u;
             if (dwaves < 64u) dwaves = 64u;
             hipLaunchKernelGGL(mp_detail_kernel, dim3(dwaves), dim3(64), 0, s, ws, dict);
         }
-        hipLaunchKernelGGL(mp_finish_kernel, dim3(blocks256), dim3(256), 0, s, ws, dict, out, quant_dev, K, step, cur,
-                           parts);
+        hipLaunchKernelGGL(mp_finish_kernel, dim3(3u * bpc), dim3(256), 0, s, ws, dict, out, quant_dev, K, step, cur, parts,
+                           (int)bpc);
     }
     return (int)hipGetLastError();
 }

@@ -50,7 +50,6 @@ struct mpc_context {
     // device residents (uploaded once)
     double* d_base = nullptr;
     double* d_detail = nullptr;
-    double* d_detail_t = nullptr;
     double* d_quant = nullptr;
     int32_t* d_rows = nullptr;
     int32_t* d_rowoff = nullptr;
@@ -72,7 +71,6 @@ mpc::DictDevice dict_device(const mpc_context* c) {
     d.num_base = c->dict.num_base;
     d.base_rows_padded = c->base_rows_padded;
     d.detail = c->d_detail;
-    d.detail_t = c->d_detail_t;
     d.detail_rows = c->dict.total_detail_rows();
     d.block_rows = c->d_rows;
     d.block_row_off = c->d_rowoff;
@@ -83,7 +81,7 @@ mpc::DictDevice dict_device(const mpc_context* c) {
 // call mpc_reserve() first
 mpc_status ensure_workspace(mpc_context* c, long long tile_channels) {
     long long cap = tile_channels < kMaxBatch ? tile_channels : kMaxBatch;
-    cap = (cap + 255) / 256 * 256;
+    cap = (cap + 767) / 768 * 768;                       // whole units (3 tile-channels) and whole 256-blocks
     if (cap <= c->ws_cap) return MPC_OK;
     if (c->d_workspace) {
         if (hipDeviceSynchronize() != hipSuccess) return fail(MPC_ERR_HIP, "device synchronise failed");
@@ -100,14 +98,20 @@ mpc_status ensure_workspace(mpc_context* c, long long tile_channels) {
     return MPC_OK;
 }
 
-// split the base sweep so that a step fills the machine ~3 waves per SIMD deep even for small batches
-int pick_parts(const mpc_context* c, long long n) {
-    const long long groups = (n + 63) / 64;
-    const long long want = 12LL * (c->num_cus > 0 ? c->num_cus : 256);
-    long long parts = (want + groups - 1) / groups;
-    if (parts < 1) parts = 1;
-    if (parts > mpc::kMaxParts) parts = mpc::kMaxParts;
-    return static_cast<int>(parts);
+// Split the 510 base atoms over `parts` waves per 64 tile-channels so that a step's grid is a whole number of
+// full machine fills (3 waves per SIMD): minimises ceil(waves / slots) * (510 / parts), smallest parts on ties.
+int pick_parts(const mpc_context* c, long long n, bool vector_mode) {
+    const long long per_list = vector_mode ? n : (n + 2) / 3;
+    const long long groups = (vector_mode ? 1 : 3) * ((per_list + 63) / 64);
+    const long long slots = 12LL * (c->num_cus > 0 ? c->num_cus : 256);
+    int best = 1;
+    double best_cost = 1e300;
+    for (int p = 1; p <= mpc::kMaxParts; ++p) {
+        const double rounds = static_cast<double>((groups * p + slots - 1) / slots);
+        const double cost = rounds * (510.0 / p + 8.0);          // + fixed per-wave cost (residual load, launch)
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = p; }
+    }
+    return best;
 }
 
 mpc_status run_pursuit(mpc_context* c, const mpc::FrameInput& in, const mpc::Outputs& out, const double* d_quant,
@@ -118,7 +122,7 @@ mpc_status run_pursuit(mpc_context* c, const mpc::FrameInput& in, const mpc::Out
     for (long long begin = 0; begin < total_tc; begin += c->ws_cap) {
         const long long n = (total_tc - begin < c->ws_cap) ? total_tc - begin : c->ws_cap;
         const int err = mpc::enqueue_pursuit(dict, c->ws, in, out, d_quant, c->K, begin, static_cast<int>(n),
-                                             pick_parts(c, n), stream);
+                                             pick_parts(c, n, in.vec_in != nullptr), stream);
         if (err != 0) return fail(MPC_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(err)));
     }
     return MPC_OK;
@@ -159,15 +163,14 @@ mpc_status mpc_context_create(int K, int block_size, double bpp, int device, mpc
         }
         hipError_t e = hipSetDevice(device);
         std::vector<double> base = mpc::base_padded(c->dict, 2, &c->base_rows_padded);
-        std::vector<double> det_t = mpc::detail_transposed(c->dict);
         const size_t det_rows = static_cast<size_t>(c->dict.total_detail_rows());
-        std::vector<double> det(3 * det_rows * mpc::kTileN);
+        // one zero row after the last: the sweep's scalar prefetch reads one row past the rows it correlates
+        std::vector<double> det((3 * det_rows + 1) * mpc::kTileN, 0.0);
         for (int ch = 0; ch < 3; ++ch)
             std::memcpy(det.data() + ch * det_rows * mpc::kTileN, c->dict.detail[ch].data(),
                         det_rows * mpc::kTileN * sizeof(double));
         if (e == hipSuccess) e = upload(&c->d_base, base.data(), base.size());
         if (e == hipSuccess) e = upload(&c->d_detail, det.data(), det.size());
-        if (e == hipSuccess) e = upload(&c->d_detail_t, det_t.data(), det_t.size());
         if (e == hipSuccess) e = upload(&c->d_quant, c->quant.data(), c->quant.size());
         if (e == hipSuccess) e = upload(&c->d_rows, c->dict.block_rows.data(), c->dict.block_rows.size());
         if (e == hipSuccess) e = upload(&c->d_rowoff, c->dict.block_row_off.data(), c->dict.block_row_off.size());
@@ -189,7 +192,6 @@ void mpc_context_destroy(mpc_context* c) {
         (void)hipSetDevice(c->device);
         (void)hipFree(c->d_base);
         (void)hipFree(c->d_detail);
-        (void)hipFree(c->d_detail_t);
         (void)hipFree(c->d_quant);
         (void)hipFree(c->d_rows);
         (void)hipFree(c->d_rowoff);
