@@ -31,6 +31,7 @@ constexpr int kMaxDeviceK = 32;
 constexpr int kMaxParts = 8;            // base sweep can be split over up to 8 atom ranges per tile-channel group
 constexpr int kChunkItems = 64;         // items (tile-channels) a wave processes per loaded detail block
 constexpr int kNumBuckets = 3 * 512;    // (channel, block) buckets, block < 510
+constexpr int kMaxRowParts = 4;         // a detail block's 62/63 rows can be split over up to 4 waves
 
 struct DictDevice {
     const double* base;              // [base_rows_padded + 1][64] row-major, zero rows after num_base
@@ -48,8 +49,8 @@ struct Workspace {
     double* r;                       // [cap][64] residuals
     double* part_val;                // [cap][kMaxParts] best projection of each base atom range
     int* part_idx;                   // [cap][kMaxParts]
-    double* cand0_val;               // [cap] best projection on DetailBasis[0] (if unlocked)
-    int* cand0_row;                  // [cap]
+    double* cand0_val;               // [cap][kMaxRowParts] best projection on DetailBasis[0] (if unlocked), per row range
+    int* cand0_row;                  // [cap][kMaxRowParts]
     int* prev_id;                    // [cap]
     int* nblk;                       // [cap] entries in blk_list
     int* extra_rows;                 // [cap] rows appended after the base part (duplicates included)
@@ -64,8 +65,10 @@ struct Workspace {
     unsigned* bucket_cursor;         // [kNumBuckets]
     int* chunks;                     // [max_chunks][4] = bucket, begin, end, 0
     int* items;                      // [max_items] tile-channel of each item
-    double* cand_val;                // [max_items] best projection of the item's block
-    int* cand_row;                   // [max_items]
+    double* cand_val;                // [max_items][kMaxRowParts] best projection of the item's block, per row range
+    int* cand_row;                   // [max_items][kMaxRowParts]
+    double* upd_coeff;               // [cap] finish -> update: coefficient of the chosen atom (0 = no update)
+    int* upd_sel;                    // [cap] ~idx for a base atom, row index into `detail` otherwise
     long long max_items;
     int max_chunks;
 };
@@ -102,7 +105,7 @@ struct HistParams {
 // (vector mode: tc = vector index, channel fixed).  Returns hipError_t as int.  No host synchronisation,
 // no allocation: graph-capturable.
 int enqueue_pursuit(const DictDevice& dict, const Workspace& ws, const FrameInput& in, const Outputs& out,
-                    const double* quant_dev, int K, long long tc_begin, int n, int parts, void* stream);
+                    const double* quant_dev, int K, long long tc_begin, int n, int parts, int row_parts, void* stream);
 
 int launch_histogram(const HistParams& p, void* stream);
 

@@ -184,13 +184,41 @@ __global__ __launch_bounds__(64, 3) void mp_base_kernel(const Workspace ws, cons
     }
 }
 
+// Row range `part` of `row_parts` of a block with `rows` rows: [lo, hi)
+__device__ __forceinline__ void row_range(int rows, int row_parts, int part, int& lo, int& hi)
+{
+    const int per = (rows + row_parts - 1) / row_parts;
+    lo = part * per;
+    hi = (lo + per < rows) ? lo + per : rows;
+    if (lo > rows) lo = rows;
+}
+
+// Pull a run of dictionary rows towards this XCD's L2 with four vector loads (one lane per 128-byte line of a
+// 32 KiB block) so that the scalar loads of the sweep, which can only keep one 128-byte group in flight, find
+// them there.  The loaded values are returned to be kept alive by the caller (summed into a dead store guard).
+__device__ __forceinline__ double touch_rows(const double* first_row, int nrows, int lane)
+{
+    double acc = 0.0;
+    const int lines = nrows * 4;                       // 512 B per row = 4 lines
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int line = k * 64 + lane;
+        if (line < lines) acc += first_row[line * 16];
+    }
+    return acc;
+}
+
 // DetailBasis[0] (unlocked by the DC atom, i.e. by nearly every tile-channel at step 0): no bucketing -- the
-// wave takes 64 consecutive entries of its channel's active list; lanes that have not unlocked block 0 idle.
-__global__ __launch_bounds__(64, 3) void mp_detail0_kernel(const Workspace ws, const DictDevice dict, int cur, int groups)
+// wave takes 64 consecutive entries of its channel's active list (lanes that have not unlocked block 0 idle)
+// and one of `row_parts` ranges of the block's 63 rows.
+__global__ __launch_bounds__(64, 3) void mp_detail0_kernel(const Workspace ws, const DictDevice dict, int cur, int groups,
+                                                           int row_parts)
 {
     const int lane = threadIdx.x;
-    const int ch = blockIdx.x / groups;
-    const int group = blockIdx.x - ch * groups;
+    const int ch = blockIdx.x / (groups * row_parts);
+    const int rem = blockIdx.x - ch * groups * row_parts;
+    const int group = rem / row_parts;
+    const int part = rem - group * row_parts;
     const int n_act = (int)scalar_counter(ws.counters, cur * 3 + ch);
     if (group * 64 >= n_act) return;
     const int pos = group * 64 + lane;
@@ -205,26 +233,30 @@ __global__ __launch_bounds__(64, 3) void mp_detail0_kernel(const Workspace ws, c
     if (!__ballot(has0)) return;
     double r[N];
     load_residual(r, ws.r + (long long)tc * N);
+    int lo, hi;
+    row_range(dict.block_rows[0], row_parts, part, lo, hi);
     double best_val;
     int best_row;
-    sweep_rows(r, as_scalar(dict.detail) + (long long)ch * dict.detail_rows * N, dict.block_rows[0], best_val, best_row);
+    sweep_rows(r, as_scalar(dict.detail) + ((long long)ch * dict.detail_rows + lo) * N, hi - lo, best_val, best_row);
     if (has0) {
-        ws.cand0_val[tc] = best_val;
-        ws.cand0_row[tc] = best_row;
+        ws.cand0_val[(long long)tc * kMaxRowParts + part] = best_val;
+        ws.cand0_row[(long long)tc * kMaxRowParts + part] = (best_row < 0) ? -1 : lo + best_row;
     }
 }
 
-// every other block: chunks of <= 64 items (tile-channels) of one (channel, block) bucket, pulled from a
-// device-side cursor; lane = item.
-__global__ __launch_bounds__(64, 3) void mp_detail_kernel(const Workspace ws, const DictDevice dict)
+// every other block: work unit = (chunk of <= 64 items of one (channel, block) bucket) x (row range);
+// lane = item.
+__global__ __launch_bounds__(64, 3) void mp_detail_kernel(const Workspace ws, const DictDevice dict, int row_parts,
+                                                          double* touch_sink)
 {
     const int lane = threadIdx.x;
-    const unsigned n_chunks = scalar_counter(ws.counters, 7);
-    for (;;) {
-        unsigned c = 0;
-        if (lane == 0) c = atomicAdd(&ws.counters[6], 1u);
-        c = (unsigned)__builtin_amdgcn_readfirstlane((int)c);
-        if (c >= n_chunks) break;
+    const unsigned n_units = scalar_counter(ws.counters, 7) * (unsigned)row_parts;
+    double keep = 0.0;
+    // static grid-stride assignment: units cost about the same, and a shared dequeue counter saturates at
+    // ~88 dequeues/us on this chip -- more than the sweeps themselves for thousands of small units
+    for (unsigned u = blockIdx.x; u < n_units; u += gridDim.x) {
+        const unsigned c = u / (unsigned)row_parts;
+        const int part = (int)(u - c * (unsigned)row_parts);
         const int* desc = ws.chunks + 4 * (long long)c;
         const int bucket = __builtin_amdgcn_readfirstlane(desc[0]);
         const int begin = __builtin_amdgcn_readfirstlane(desc[1]);
@@ -232,19 +264,22 @@ __global__ __launch_bounds__(64, 3) void mp_detail_kernel(const Workspace ws, co
         const int ch = bucket >> 9, blk = bucket & 511;
         const int cnt = end - begin;
         const bool valid = lane < cnt;
+        int lo, hi;
+        row_range(dict.block_rows[blk], row_parts, part, lo, hi);
+        const long long first = (long long)ch * dict.detail_rows + dict.block_row_off[blk] + lo;
+        keep += touch_rows(dict.detail + first * N, hi - lo, lane);
         const int tc = ws.items[begin + (valid ? lane : 0)];
         double r[N];
         load_residual(r, ws.r + (long long)tc * N);
-        const int rows = dict.block_rows[blk];
-        const long long first = (long long)ch * dict.detail_rows + dict.block_row_off[blk];
         double best_val;
         int best_row;
-        sweep_rows(r, as_scalar(dict.detail) + first * N, rows, best_val, best_row);
+        sweep_rows(r, as_scalar(dict.detail) + first * N, hi - lo, best_val, best_row);
         if (valid) {
-            ws.cand_val[begin + lane] = best_val;
-            ws.cand_row[begin + lane] = best_row;
+            ws.cand_val[(long long)(begin + lane) * kMaxRowParts + part] = best_val;
+            ws.cand_row[(long long)(begin + lane) * kMaxRowParts + part] = (best_row < 0) ? -1 : lo + best_row;
         }
     }
+    if (keep == 123456.789) touch_sink[lane] = keep;          // never true: keeps the touch loads alive
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -325,7 +360,7 @@ __global__ __launch_bounds__(256) void mp_fill_kernel(const Workspace ws, int cu
 // --------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void mp_finish_kernel(const Workspace ws, const DictDevice dict, const Outputs out,
                                                        const double* __restrict__ quant, int K, int step, int cur,
-                                                       int parts, int blocks_per_channel)
+                                                       int parts, int row_parts, int blocks_per_channel)
 {
     const int ch = blockIdx.x / blocks_per_channel;
     const int n_act = (int)ws.counters[cur * 3 + ch];
@@ -351,16 +386,20 @@ __global__ __launch_bounds__(256) void mp_finish_kernel(const Workspace ws, cons
         const int blk = (int)(e & 0x7FFFu);
         const int rows = dict.block_rows[blk];
         if (!(e & 0x8000u)) {               // a repeated block can never win: identical projections at a higher index
-            double v;
-            int row;
-            if (blk == 0) { v = ws.cand0_val[tc]; row = ws.cand0_row[tc]; }
+            const double* cv;
+            const int* cr;
+            if (blk == 0) { cv = ws.cand0_val + (long long)tc * kMaxRowParts; cr = ws.cand0_row + (long long)tc * kMaxRowParts; }
             else {
-                const int slot = ws.item_slot[(long long)tc * kMaxDeviceK + i];
-                v = ws.cand_val[slot];
-                row = ws.cand_row[slot];
+                const long long slot = ws.item_slot[(long long)tc * kMaxDeviceK + i];
+                cv = ws.cand_val + slot * kMaxRowParts;
+                cr = ws.cand_row + slot * kMaxRowParts;
             }
-            if (row >= 0 && __builtin_fabs(v) > __builtin_fabs(best_val)) {
-                best_val = v; best_idx = off + row; best_sel = dict.block_row_off[blk] + row;
+            for (int p = 0; p < row_parts; ++p) {       // row ranges in ascending order
+                const double v = cv[p];
+                const int row = cr[p];
+                if (row >= 0 && __builtin_fabs(v) > __builtin_fabs(best_val)) {
+                    best_val = v; best_idx = off + row; best_sel = dict.block_row_off[blk] + row;
+                }
             }
         }
         off += rows;
@@ -368,11 +407,12 @@ __global__ __launch_bounds__(256) void mp_finish_kernel(const Workspace ws, cons
     const unsigned swept = ws.swept[tc] + (unsigned)(dict.num_base + extra);
     ws.swept[tc] = swept;
 
-    double* r = ws.r + (long long)tc * N;
+    const double* r = ws.r + (long long)tc * N;
     bool done = false;
     int count = 0;
     unsigned record = 0;
     bool unlocked = false;
+    double coeff = 0.0;
     if (best_idx < 0) {                                       // MatchingPursuit.cpp:50-54
         done = true; count = step;
     } else {
@@ -387,13 +427,7 @@ __global__ __launch_bounds__(256) void mp_finish_kernel(const Workspace ws, cons
         if (q == 0) {                                         // :66-69
             done = true; count = step;
         } else {
-            const double coeff = qstep * (double)q;
-            const double* row = (best_sel < 0) ? (dict.base + (long long)(~best_sel) * N)
-                                               : (dict.detail + ((long long)ch * dict.detail_rows + best_sel) * N);
-            for (int j = 0; j < N; ++j) {
-                const double scaled = coeff * row[j];         // Vector::Scale
-                r[j] = r[j] - scaled;                         // Vector::Subtract
-            }
+            coeff = qstep * (double)q;                        // residual update itself: mp_update_kernel (coalesced)
             if (best_idx < dict.num_base) {                   // unlock DetailBasis[choice]; duplicates are appended again
                 unsigned e = (unsigned)best_idx;
                 for (int i = 0; i < nb; ++i)
@@ -407,11 +441,23 @@ __global__ __launch_bounds__(256) void mp_finish_kernel(const Workspace ws, cons
         }
     }
     out.choices[rec * K + step] = record;
+    ws.upd_coeff[tc] = coeff;
+    ws.upd_sel[tc] = best_sel;
     if (done) {
+        // energy of the final residual, sequential like the oracle; when this step still subtracts an atom
+        // (count == K) the subtraction is folded in with the same two roundings as the update kernel
+        const double* row = (best_sel < 0) ? (dict.base + (long long)(~best_sel) * N)
+                                           : (dict.detail + ((long long)ch * dict.detail_rows + best_sel) * N);
         double e2 = 0.0;
-        for (int j = 0; j < N; ++j) e2 += r[j] * r[j];
+        if (out.energy) {
+            for (int j = 0; j < N; ++j) {
+                double v = r[j];
+                if (coeff != 0.0) { const double scaled = coeff * row[j]; v = v - scaled; }
+                e2 += v * v;
+            }
+            out.energy[rec] = e2;
+        }
         out.counts[rec] = (uint16_t)count;
-        if (out.energy) out.energy[rec] = e2;
         if (out.swept) out.swept[rec] = swept;
     } else {
         // wave-aggregated append to the channel's next active list (the wave is channel-pure)
@@ -433,21 +479,96 @@ __global__ __launch_bounds__(256) void mp_finish_kernel(const Workspace ws, cons
     }
 }
 
+// update: r -= coeff * atom for every tile-channel the finish kernel quantised to a non-zero coefficient
+// (Vector::Scale then Vector::Subtract, mathvector.cpp:116-148: two roundings).  One wave per 64 entries of
+// the active list, LANE = PIXEL: each residual and atom row is one coalesced 512-byte access.
+__global__ __launch_bounds__(64) void mp_update_kernel(const Workspace ws, const DictDevice dict, int cur, int groups)
+{
+    const int lane = threadIdx.x;
+    const int ch = blockIdx.x / groups;
+    const int group = blockIdx.x - ch * groups;
+    const int n_act = (int)scalar_counter(ws.counters, cur * 3 + ch);
+    if (group * 64 >= n_act) return;
+    const int pos = group * 64 + lane;
+    int tc = 0, sel = 0;
+    double coeff = 0.0;
+    if (pos < n_act) {
+        tc = ws.act[cur][ch][pos];
+        coeff = ws.upd_coeff[tc];
+        sel = ws.upd_sel[tc];
+    }
+    if (!__ballot(coeff != 0.0)) return;
+    const int c_lo = __double2loint(coeff), c_hi = __double2hiint(coeff);
+    // fixed batches of 8 tile-channels: 16 independent coalesced loads in flight, then the stores
+    // (entries that do not update keep coeff 0 and are not stored)
+#pragma unroll 1
+    for (int base = 0; base < 64; base += 8) {
+        double rv[8], av[8], cv[8];
+        double* rp[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int p = base + k;
+            const int tci = __builtin_amdgcn_readlane(tc, p);
+            const int seli = __builtin_amdgcn_readlane(sel, p);
+            cv[k] = __hiloint2double(__builtin_amdgcn_readlane(c_hi, p), __builtin_amdgcn_readlane(c_lo, p));
+            const double* row = (seli < 0) ? (dict.base + (long long)(~seli) * N)
+                                           : (dict.detail + ((long long)ch * dict.detail_rows + seli) * N);
+            rp[k] = ws.r + (long long)tci * N + lane;
+            rv[k] = *rp[k];
+            av[k] = row[lane];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (cv[k] != 0.0) {
+                const double scaled = cv[k] * av[k];      // Vector::Scale
+                *rp[k] = rv[k] - scaled;                   // Vector::Subtract
+            }
+        }
+    }
+}
+
 // Per-stream symbol histograms for the Huffman/Golomb stage (RCCL all-reduce input):
 // stream 0 = lengths, stream 1 + 2K*ch + 2i (+1) = codes[2K*ch + 2i (+1)] (CompressedImage.cpp:556-572).
-__global__ __launch_bounds__(256) void mp_histogram_kernel(const HistParams p)
+// Block (job, slice): job 0 counts the lengths of all tile-channels, job 1 + ch*K + i counts the deltaId and
+// intCoeff symbols of step i of channel ch; a job's tiles are split over `slices` blocks.  Counting is done in
+// LDS (two 8192-bin tables), only non-zero bins are flushed with global atomics.
+__global__ __launch_bounds__(256) void mp_histogram_kernel(const HistParams p, int slices)
 {
-    const long long n = p.tiles * 3;
-    for (long long o = blockIdx.x * (long long)blockDim.x + threadIdx.x; o < n; o += (long long)gridDim.x * blockDim.x) {
-        const int ch = (int)(o % 3);
-        const int cnt = p.counts[o];
-        atomicAdd(&p.hist[cnt & (kHistBins - 1)], 1u);
-        for (int i = 0; i < cnt; ++i) {
-            const uint32_t rec = p.choices[o * p.K + i];
-            const int s = 1 + 2 * p.K * ch + 2 * i;
-            atomicAdd(&p.hist[(long long)s * kHistBins + (rec & 0xFFFFu & (kHistBins - 1))], 1u);
-            atomicAdd(&p.hist[(long long)(s + 1) * kHistBins + ((rec >> 16) & (kHistBins - 1))], 1u);
+    __shared__ unsigned h0[kHistBins];
+    __shared__ unsigned h1[kHistBins];
+    const int job = blockIdx.x / slices;
+    const int slice = blockIdx.x - job * slices;
+    for (int b = threadIdx.x; b < kHistBins; b += blockDim.x) { h0[b] = 0; h1[b] = 0; }
+    __syncthreads();
+    const long long per = (p.tiles + slices - 1) / slices;
+    const long long t0 = slice * per;
+    const long long t1 = (t0 + per < p.tiles) ? t0 + per : p.tiles;
+    if (job == 0) {
+        for (long long o = t0 * 3 + threadIdx.x; o < t1 * 3; o += blockDim.x)
+            atomicAdd(&h0[p.counts[o] & (kHistBins - 1)], 1u);
+    } else {
+        const int ch = (job - 1) / p.K, i = (job - 1) - ch * p.K;
+        for (long long t = t0 + threadIdx.x; t < t1; t += blockDim.x) {
+            const long long o = t * 3 + ch;
+            if (p.counts[o] > i) {
+                const uint32_t rec = p.choices[o * p.K + i];
+                atomicAdd(&h0[rec & 0xFFFFu & (kHistBins - 1)], 1u);
+                atomicAdd(&h1[(rec >> 16) & (kHistBins - 1)], 1u);
+            }
         }
+    }
+    __syncthreads();
+    uint32_t* g0;
+    uint32_t* g1 = nullptr;
+    if (job == 0) g0 = p.hist;
+    else {
+        const int ch = (job - 1) / p.K, i = (job - 1) - ch * p.K;
+        g0 = p.hist + (long long)(1 + 2 * p.K * ch + 2 * i) * kHistBins;
+        g1 = g0 + kHistBins;
+    }
+    for (int b = threadIdx.x; b < kHistBins; b += blockDim.x) {
+        if (h0[b]) atomicAdd(&g0[b], h0[b]);
+        if (g1 && h1[b]) atomicAdd(&g1[b], h1[b]);
     }
 }
 
@@ -488,8 +609,10 @@ Workspace carve(char* mem, int cap, int K, size_t* total)
     w.out_index = c.take<int>(n);
     for (int a = 0; a < 2; ++a)
         for (int ch = 0; ch < 3; ++ch) w.act[a][ch] = c.take<int>(n);
-    w.cand0_val = c.take<double>(n);
-    w.cand0_row = c.take<int>(n);
+    w.cand0_val = c.take<double>(n * kMaxRowParts);
+    w.cand0_row = c.take<int>(n * kMaxRowParts);
+    w.upd_coeff = c.take<double>(n);
+    w.upd_sel = c.take<int>(n);
     w.counters = c.take<unsigned>(16);
     w.bucket_count[0] = c.take<unsigned>(kNumBuckets);
     w.bucket_count[1] = c.take<unsigned>(kNumBuckets);
@@ -497,8 +620,8 @@ Workspace carve(char* mem, int cap, int K, size_t* total)
     w.bucket_cursor = c.take<unsigned>(kNumBuckets);
     w.chunks = c.take<int>(static_cast<size_t>(w.max_chunks) * 4);
     w.items = c.take<int>(static_cast<size_t>(w.max_items));
-    w.cand_val = c.take<double>(static_cast<size_t>(w.max_items));
-    w.cand_row = c.take<int>(static_cast<size_t>(w.max_items));
+    w.cand_val = c.take<double>(static_cast<size_t>(w.max_items) * kMaxRowParts);
+    w.cand_row = c.take<int>(static_cast<size_t>(w.max_items) * kMaxRowParts);
     if (total) *total = c.off;
     return w;
 }
@@ -514,12 +637,14 @@ size_t workspace_bytes(int cap, int K)
 Workspace carve_workspace(void* device_mem, int cap, int K) { return carve(static_cast<char*>(device_mem), cap, K, nullptr); }
 
 int enqueue_pursuit(const DictDevice& dict, const Workspace& ws, const FrameInput& in, const Outputs& out,
-                    const double* quant_dev, int K, long long tc_begin, int n, int parts, void* stream_)
+                    const double* quant_dev, int K, long long tc_begin, int n, int parts, int row_parts, void* stream_)
 {
     hipStream_t s = static_cast<hipStream_t>(stream_);
     if (n < 1 || n > ws.cap) return (int)hipErrorInvalidValue;
     if (parts < 1) parts = 1;
     if (parts > kMaxParts) parts = kMaxParts;
+    if (row_parts < 1) row_parts = 1;
+    if (row_parts > kMaxRowParts) row_parts = kMaxRowParts;
     // per-channel list capacity: n/3 units in tile mode (batches hold whole units), n in vector mode
     const int per_list = in.vec_in ? n : (n + 2) / 3;
     const unsigned groups = (unsigned)((per_list + 63) / 64);
@@ -535,25 +660,28 @@ int enqueue_pursuit(const DictDevice& dict, const Workspace& ws, const FrameInpu
         hipLaunchKernelGGL(mp_base_kernel, dim3(3u * groups * (unsigned)parts), dim3(64), 0, s, ws, dict, cur, (int)groups,
                            parts);
         if (step > 0) {
-            hipLaunchKernelGGL(mp_detail0_kernel, dim3(3u * groups), dim3(64), 0, s, ws, dict, cur, (int)groups);
-            unsigned dwaves = 3u * groups;
+            hipLaunchKernelGGL(mp_detail0_kernel, dim3(3u * groups * (unsigned)row_parts), dim3(64), 0, s, ws, dict, cur,
+                               (int)groups, row_parts);
+            unsigned dwaves = 3u * groups * (unsigned)row_parts;
             if (dwaves > 6144u) dwaves = 6144u;
             if (dwaves < 64u) dwaves = 64u;
-            hipLaunchKernelGGL(mp_detail_kernel, dim3(dwaves), dim3(64), 0, s, ws, dict);
+            hipLaunchKernelGGL(mp_detail_kernel, dim3(dwaves), dim3(64), 0, s, ws, dict, row_parts, ws.cand_val);
         }
         hipLaunchKernelGGL(mp_finish_kernel, dim3(3u * bpc), dim3(256), 0, s, ws, dict, out, quant_dev, K, step, cur, parts,
-                           (int)bpc);
+                           row_parts, (int)bpc);
+        if (step + 1 < K)
+            hipLaunchKernelGGL(mp_update_kernel, dim3(3u * groups), dim3(64), 0, s, ws, dict, cur, (int)groups);
     }
     return (int)hipGetLastError();
 }
 
 int launch_histogram(const HistParams& p, void* stream)
 {
-    long long n = p.tiles * 3;
-    int blocks = (int)((n + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(mp_histogram_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+    const int jobs = 1 + 3 * p.K;
+    int slices = (int)((p.tiles + 8191) / 8192);       // ~8k tiles per block
+    if (slices < 1) slices = 1;
+    if (slices > 64) slices = 64;
+    hipLaunchKernelGGL(mp_histogram_kernel, dim3((unsigned)(jobs * slices)), dim3(256), 0, (hipStream_t)stream, p, slices);
     return (int)hipGetLastError();
 }
 

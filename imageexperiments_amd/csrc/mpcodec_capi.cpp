@@ -114,6 +114,16 @@ int pick_parts(const mpc_context* c, long long n, bool vector_mode) {
     return best;
 }
 
+// Small batches do not have enough (bucket, chunk) units to fill the machine: split each block's rows too.
+int pick_row_parts(const mpc_context* c, long long n, bool vector_mode) {
+    const long long per_list = vector_mode ? n : (n + 2) / 3;
+    const long long groups = (vector_mode ? 1 : 3) * ((per_list + 63) / 64);
+    const long long slots = 12LL * (c->num_cus > 0 ? c->num_cus : 256);
+    if (groups >= 2 * slots) return 1;
+    if (groups >= slots) return 2;
+    return mpc::kMaxRowParts;
+}
+
 mpc_status run_pursuit(mpc_context* c, const mpc::FrameInput& in, const mpc::Outputs& out, const double* d_quant,
                        long long total_tc, void* stream) {
     mpc_status st = ensure_workspace(c, total_tc);
@@ -122,7 +132,8 @@ mpc_status run_pursuit(mpc_context* c, const mpc::FrameInput& in, const mpc::Out
     for (long long begin = 0; begin < total_tc; begin += c->ws_cap) {
         const long long n = (total_tc - begin < c->ws_cap) ? total_tc - begin : c->ws_cap;
         const int err = mpc::enqueue_pursuit(dict, c->ws, in, out, d_quant, c->K, begin, static_cast<int>(n),
-                                             pick_parts(c, n, in.vec_in != nullptr), stream);
+                                             pick_parts(c, n, in.vec_in != nullptr),
+                                             pick_row_parts(c, n, in.vec_in != nullptr), stream);
         if (err != 0) return fail(MPC_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(err)));
     }
     return MPC_OK;

@@ -132,3 +132,25 @@ def test_row_stripes_equal_full_frame(ctx32, oracle):
         for arr_full, arr_part in zip(full, part):
             f = arr_full.reshape((tx, ty) + arr_full.shape[1:])[:, a:b]
             assert (f.reshape((tx * rows,) + arr_full.shape[1:]) == arr_part).all()
+
+
+def test_histogram_matches_numpy(gpu, ctx32, oracle):
+    """per-stream symbol histograms (the RCCL all-reduce operand) == numpy bincount of the records."""
+    import torch
+    rgb = oracle.synth_frame(160, 96, 31)
+    counts, choices, energy, swept = ctx32.encode_tiles(rgb)
+    T, K = counts.shape[0], 32
+    d_counts = torch.from_numpy(counts.astype(np.int16)).cuda()
+    d_choices = torch.from_numpy(choices.view(np.uint32).astype(np.int64).astype(np.int32).reshape(T, 3, K)).cuda()
+    d_hist = torch.zeros((1 + 6 * K, 8192), dtype=torch.int32, device="cuda")
+    ctx32.histogram_device(d_counts.data_ptr(), d_choices.data_ptr(), T, d_hist.data_ptr())
+    torch.cuda.synchronize()
+    hist = d_hist.cpu().numpy()
+    ref = np.zeros_like(hist)
+    ref[0] = np.bincount(counts.reshape(-1), minlength=8192)
+    for ch in range(3):
+        for i in range(K):
+            m = counts[:, ch] > i
+            ref[1 + 2 * K * ch + 2 * i] = np.bincount(choices["deltaId"][m, ch, i], minlength=8192)
+            ref[2 + 2 * K * ch + 2 * i] = np.bincount(choices["intCoeff"][m, ch, i], minlength=8192)
+    assert (hist == ref).all()
