@@ -105,7 +105,8 @@ struct HistParams {
 // (vector mode: tc = vector index, channel fixed).  Returns hipError_t as int.  No host synchronisation,
 // no allocation: graph-capturable.
 int enqueue_pursuit(const DictDevice& dict, const Workspace& ws, const FrameInput& in, const Outputs& out,
-                    const double* quant_dev, int K, long long tc_begin, int n, int parts, int row_parts, void* stream);
+                    const double* quant_dev, int K, long long tc_begin, int n, int parts, int row_parts, int sweep_waves,
+                    void* stream);
 
 int launch_histogram(const HistParams& p, void* stream);
 

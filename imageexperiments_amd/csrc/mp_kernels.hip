@@ -154,33 +154,64 @@ __device__ __forceinline__ unsigned scalar_counter(const unsigned* counters, int
 
 }  // namespace
 
-// base sweep: grid = 3 channels x groups x parts.  One wave = 64 entries of one channel's active list x one
-// range of the 510 base atoms; the ranges are combined in index order by the finish kernel.
-__global__ __launch_bounds__(64, 3) void mp_base_kernel(const Workspace ws, const DictDevice dict, int cur, int groups,
-                                                        int parts)
+// Work-unit decoding shared by the sweep kernels: the three per-channel active lists are cut into groups of 64
+// entries; unit u of a kernel = (sub-range `part`, group).  Units are numbered part-major so that waves running
+// at the same time sweep the same dictionary rows (scalar-cache / L2 locality).  Grids are persistent
+// (gridDim = a few waves per SIMD) and stride over the units, whose number is only known on the device.
+struct UnitMap {
+    int g0, g1, g2;            // groups per channel
+    __device__ int groups() const { return g0 + g1 + g2; }
+};
+
+__device__ __forceinline__ UnitMap unit_map(const unsigned* counters, int cur)
+{
+    UnitMap m;
+    m.g0 = ((int)scalar_counter(counters, cur * 3 + 0) + 63) >> 6;
+    m.g1 = ((int)scalar_counter(counters, cur * 3 + 1) + 63) >> 6;
+    m.g2 = ((int)scalar_counter(counters, cur * 3 + 2) + 63) >> 6;
+    return m;
+}
+
+__device__ __forceinline__ void decode_group(const UnitMap& m, int gi, int& ch, int& group)
+{
+    int c, g;
+    if (gi < m.g0) { c = 0; g = gi; }
+    else if (gi < m.g0 + m.g1) { c = 1; g = gi - m.g0; }
+    else { c = 2; g = gi - m.g0 - m.g1; }
+    // wave-uniform by construction; say so, or the dictionary-row loads that depend on them stop being scalar
+    ch = __builtin_amdgcn_readfirstlane(c);
+    group = __builtin_amdgcn_readfirstlane(g);
+}
+
+// base sweep: unit = 64 entries of one channel's active list x one of `parts` ranges of the 510 base atoms;
+// the ranges are combined in index order by the finish kernel.
+__global__ __launch_bounds__(64, 3) void mp_base_kernel(const Workspace ws, const DictDevice dict, int cur, int parts)
 {
     const int lane = threadIdx.x;
-    const int ch = blockIdx.x / (groups * parts);
-    const int rem = blockIdx.x - ch * groups * parts;
-    const int group = rem / parts;
-    const int part = rem - group * parts;
     if (blockIdx.x == 0 && lane < 3) ws.counters[(cur ^ 1) * 3 + lane] = 0;      // next step's active counts
-    const int n_act = (int)scalar_counter(ws.counters, cur * 3 + ch);
-    if (group * 64 >= n_act) return;
-    const int pos = group * 64 + lane;
-    const bool valid = pos < n_act;
-    const int tc = ws.act[cur][ch][valid ? pos : group * 64];
-    double r[N];
-    load_residual(r, ws.r + (long long)tc * N);
+    const UnitMap m = unit_map(ws.counters, cur);
+    const int total_groups = m.groups();
+    const int n_units = total_groups * parts;
     const int per = (dict.base_rows_padded + parts - 1) / parts;
-    const int a0 = part * per;
-    const int a1 = (a0 + per < dict.base_rows_padded) ? a0 + per : dict.base_rows_padded;
-    double best_val;
-    int best_row;
-    sweep_rows(r, as_scalar(dict.base) + (long long)a0 * N, a1 - a0, best_val, best_row);
-    if (valid) {
-        ws.part_val[(long long)tc * kMaxParts + part] = best_val;
-        ws.part_idx[(long long)tc * kMaxParts + part] = (best_row < 0) ? -1 : a0 + best_row;
+    for (int u = blockIdx.x; u < n_units; u += gridDim.x) {
+        const int part = __builtin_amdgcn_readfirstlane(u / total_groups);
+        int ch, group;
+        decode_group(m, u - part * total_groups, ch, group);
+        const int n_act = (int)scalar_counter(ws.counters, cur * 3 + ch);
+        const int pos = group * 64 + lane;
+        const bool valid = pos < n_act;
+        const int tc = ws.act[cur][ch][valid ? pos : group * 64];
+        double r[N];
+        load_residual(r, ws.r + (long long)tc * N);
+        const int a0 = part * per;
+        const int a1 = (a0 + per < dict.base_rows_padded) ? a0 + per : dict.base_rows_padded;
+        double best_val;
+        int best_row;
+        sweep_rows(r, as_scalar(dict.base) + (long long)a0 * N, a1 - a0, best_val, best_row);
+        if (valid) {
+            ws.part_val[(long long)tc * kMaxParts + part] = best_val;
+            ws.part_idx[(long long)tc * kMaxParts + part] = (best_row < 0) ? -1 : a0 + best_row;
+        }
     }
 }
 
@@ -208,39 +239,42 @@ __device__ __forceinline__ double touch_rows(const double* first_row, int nrows,
     return acc;
 }
 
-// DetailBasis[0] (unlocked by the DC atom, i.e. by nearly every tile-channel at step 0): no bucketing -- the
-// wave takes 64 consecutive entries of its channel's active list (lanes that have not unlocked block 0 idle)
-// and one of `row_parts` ranges of the block's 63 rows.
-__global__ __launch_bounds__(64, 3) void mp_detail0_kernel(const Workspace ws, const DictDevice dict, int cur, int groups,
-                                                           int row_parts)
+// DetailBasis[0] (unlocked by the DC atom, i.e. by nearly every tile-channel at step 0): no bucketing -- a unit
+// is 64 consecutive entries of a channel's active list (lanes that have not unlocked block 0 idle) x one of
+// `row_parts` ranges of the block's 63 rows.
+__global__ __launch_bounds__(64, 3) void mp_detail0_kernel(const Workspace ws, const DictDevice dict, int cur, int row_parts)
 {
     const int lane = threadIdx.x;
-    const int ch = blockIdx.x / (groups * row_parts);
-    const int rem = blockIdx.x - ch * groups * row_parts;
-    const int group = rem / row_parts;
-    const int part = rem - group * row_parts;
-    const int n_act = (int)scalar_counter(ws.counters, cur * 3 + ch);
-    if (group * 64 >= n_act) return;
-    const int pos = group * 64 + lane;
-    const bool valid = pos < n_act;
-    const int tc = ws.act[cur][ch][valid ? pos : group * 64];
-    bool has0 = false;
-    if (valid) {
-        const int nb = ws.nblk[tc];
-        for (int i = 0; i < nb; ++i)
-            if (ws.blk_list[(long long)tc * kMaxDeviceK + i] == 0) has0 = true;         // first occurrence of block 0
-    }
-    if (!__ballot(has0)) return;
-    double r[N];
-    load_residual(r, ws.r + (long long)tc * N);
-    int lo, hi;
-    row_range(dict.block_rows[0], row_parts, part, lo, hi);
-    double best_val;
-    int best_row;
-    sweep_rows(r, as_scalar(dict.detail) + ((long long)ch * dict.detail_rows + lo) * N, hi - lo, best_val, best_row);
-    if (has0) {
-        ws.cand0_val[(long long)tc * kMaxRowParts + part] = best_val;
-        ws.cand0_row[(long long)tc * kMaxRowParts + part] = (best_row < 0) ? -1 : lo + best_row;
+    const UnitMap m = unit_map(ws.counters, cur);
+    const int total_groups = m.groups();
+    const int n_units = total_groups * row_parts;
+    const int rows0 = dict.block_rows[0];
+    for (int u = blockIdx.x; u < n_units; u += gridDim.x) {
+        const int part = __builtin_amdgcn_readfirstlane(u / total_groups);
+        int ch, group;
+        decode_group(m, u - part * total_groups, ch, group);
+        const int n_act = (int)scalar_counter(ws.counters, cur * 3 + ch);
+        const int pos = group * 64 + lane;
+        const bool valid = pos < n_act;
+        const int tc = ws.act[cur][ch][valid ? pos : group * 64];
+        bool has0 = false;
+        if (valid) {
+            const int nb = ws.nblk[tc];
+            for (int i = 0; i < nb; ++i)
+                if (ws.blk_list[(long long)tc * kMaxDeviceK + i] == 0) has0 = true;     // first occurrence of block 0
+        }
+        if (!__ballot(has0)) continue;
+        double r[N];
+        load_residual(r, ws.r + (long long)tc * N);
+        int lo, hi;
+        row_range(rows0, row_parts, part, lo, hi);
+        double best_val;
+        int best_row;
+        sweep_rows(r, as_scalar(dict.detail) + ((long long)ch * dict.detail_rows + lo) * N, hi - lo, best_val, best_row);
+        if (has0) {
+            ws.cand0_val[(long long)tc * kMaxRowParts + part] = best_val;
+            ws.cand0_row[(long long)tc * kMaxRowParts + part] = (best_row < 0) ? -1 : lo + best_row;
+        }
     }
 }
 
@@ -255,8 +289,9 @@ __global__ __launch_bounds__(64, 3) void mp_detail_kernel(const Workspace ws, co
     // static grid-stride assignment: units cost about the same, and a shared dequeue counter saturates at
     // ~88 dequeues/us on this chip -- more than the sweeps themselves for thousands of small units
     for (unsigned u = blockIdx.x; u < n_units; u += gridDim.x) {
-        const unsigned c = u / (unsigned)row_parts;
-        const int part = (int)(u - c * (unsigned)row_parts);
+        const unsigned n_chunks = n_units / (unsigned)row_parts;
+        const int part = __builtin_amdgcn_readfirstlane((int)(u / n_chunks));
+        const unsigned c = u - (unsigned)part * n_chunks;
         const int* desc = ws.chunks + 4 * (long long)c;
         const int bucket = __builtin_amdgcn_readfirstlane(desc[0]);
         const int begin = __builtin_amdgcn_readfirstlane(desc[1]);
@@ -265,8 +300,8 @@ __global__ __launch_bounds__(64, 3) void mp_detail_kernel(const Workspace ws, co
         const int cnt = end - begin;
         const bool valid = lane < cnt;
         int lo, hi;
-        row_range(dict.block_rows[blk], row_parts, part, lo, hi);
-        const long long first = (long long)ch * dict.detail_rows + dict.block_row_off[blk] + lo;
+        row_range(__builtin_amdgcn_readfirstlane(dict.block_rows[blk]), row_parts, part, lo, hi);
+        const long long first = (long long)ch * dict.detail_rows + __builtin_amdgcn_readfirstlane(dict.block_row_off[blk]) + lo;
         keep += touch_rows(dict.detail + first * N, hi - lo, lane);
         const int tc = ws.items[begin + (valid ? lane : 0)];
         double r[N];
@@ -335,12 +370,16 @@ __global__ __launch_bounds__(1024) void mp_bucket_kernel(const Workspace ws, int
 
 // fill: each active tile-channel drops one item per unlocked, non-repeated block (block 0 excepted) into
 // that block's bucket and remembers the slot.
-__global__ __launch_bounds__(256) void mp_fill_kernel(const Workspace ws, int cur, int blocks_per_channel)
+__global__ __launch_bounds__(256) void mp_fill_kernel(const Workspace ws, int cur)
 {
-    const int ch = blockIdx.x / blocks_per_channel;
+    // grid-stride over 256-entry slabs of the three active lists
+    const int s0 = ((int)ws.counters[cur * 3 + 0] + 255) >> 8, s1 = ((int)ws.counters[cur * 3 + 1] + 255) >> 8,
+              s2 = ((int)ws.counters[cur * 3 + 2] + 255) >> 8;
+    for (int slab = blockIdx.x; slab < s0 + s1 + s2; slab += gridDim.x) {
+    const int ch = slab < s0 ? 0 : (slab < s0 + s1 ? 1 : 2);
     const int n_act = (int)ws.counters[cur * 3 + ch];
-    const int pos = (blockIdx.x - ch * blocks_per_channel) * blockDim.x + threadIdx.x;
-    if (pos >= n_act) return;
+    const int pos = (slab - (ch == 0 ? 0 : (ch == 1 ? s0 : s0 + s1))) * 256 + (int)threadIdx.x;
+    if (pos >= n_act) continue;
     const int tc = ws.act[cur][ch][pos];
     const int nb = ws.nblk[tc];
     for (int i = 0; i < nb; ++i) {
@@ -351,6 +390,7 @@ __global__ __launch_bounds__(256) void mp_fill_kernel(const Workspace ws, int cu
         ws.items[slot] = tc;
         ws.item_slot[(long long)tc * kMaxDeviceK + i] = (int)slot;
     }
+    }
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -360,12 +400,15 @@ __global__ __launch_bounds__(256) void mp_fill_kernel(const Workspace ws, int cu
 // --------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void mp_finish_kernel(const Workspace ws, const DictDevice dict, const Outputs out,
                                                        const double* __restrict__ quant, int K, int step, int cur,
-                                                       int parts, int row_parts, int blocks_per_channel)
+                                                       int parts, int row_parts)
 {
-    const int ch = blockIdx.x / blocks_per_channel;
+    const int s0 = ((int)ws.counters[cur * 3 + 0] + 255) >> 8, s1 = ((int)ws.counters[cur * 3 + 1] + 255) >> 8,
+              s2 = ((int)ws.counters[cur * 3 + 2] + 255) >> 8;
+    for (int slab = blockIdx.x; slab < s0 + s1 + s2; slab += gridDim.x) {
+    const int ch = slab < s0 ? 0 : (slab < s0 + s1 ? 1 : 2);
     const int n_act = (int)ws.counters[cur * 3 + ch];
-    const int pos = (blockIdx.x - ch * blocks_per_channel) * blockDim.x + threadIdx.x;
-    if (pos >= n_act) return;
+    const int pos = (slab - (ch == 0 ? 0 : (ch == 1 ? s0 : s0 + s1))) * 256 + (int)threadIdx.x;
+    if (pos >= n_act) continue;
     const int tc = ws.act[cur][ch][pos];
     const unsigned oi = (unsigned)ws.out_index[tc];
     const long long rec = (long long)(oi & 0x3FFFFFFFu);
@@ -477,18 +520,21 @@ __global__ __launch_bounds__(256) void mp_finish_kernel(const Workspace ws, cons
             atomicAdd(&cnt[(ch << 9) | (int)e], 1u);
         }
     }
+    }
 }
 
 // update: r -= coeff * atom for every tile-channel the finish kernel quantised to a non-zero coefficient
 // (Vector::Scale then Vector::Subtract, mathvector.cpp:116-148: two roundings).  One wave per 64 entries of
 // the active list, LANE = PIXEL: each residual and atom row is one coalesced 512-byte access.
-__global__ __launch_bounds__(64) void mp_update_kernel(const Workspace ws, const DictDevice dict, int cur, int groups)
+__global__ __launch_bounds__(64) void mp_update_kernel(const Workspace ws, const DictDevice dict, int cur)
 {
     const int lane = threadIdx.x;
-    const int ch = blockIdx.x / groups;
-    const int group = blockIdx.x - ch * groups;
+    const UnitMap m = unit_map(ws.counters, cur);
+    const int total_groups = m.groups();
+    for (int gi = blockIdx.x; gi < total_groups; gi += gridDim.x) {
+    int ch, group;
+    decode_group(m, gi, ch, group);
     const int n_act = (int)scalar_counter(ws.counters, cur * 3 + ch);
-    if (group * 64 >= n_act) return;
     const int pos = group * 64 + lane;
     int tc = 0, sel = 0;
     double coeff = 0.0;
@@ -497,7 +543,7 @@ __global__ __launch_bounds__(64) void mp_update_kernel(const Workspace ws, const
         coeff = ws.upd_coeff[tc];
         sel = ws.upd_sel[tc];
     }
-    if (!__ballot(coeff != 0.0)) return;
+    if (!__ballot(coeff != 0.0)) continue;
     const int c_lo = __double2loint(coeff), c_hi = __double2hiint(coeff);
     // fixed batches of 8 tile-channels: 16 independent coalesced loads in flight, then the stores
     // (entries that do not update keep coeff 0 and are not stored)
@@ -524,6 +570,7 @@ __global__ __launch_bounds__(64) void mp_update_kernel(const Workspace ws, const
                 *rp[k] = rv[k] - scaled;                   // Vector::Subtract
             }
         }
+    }
     }
 }
 
@@ -637,7 +684,8 @@ size_t workspace_bytes(int cap, int K)
 Workspace carve_workspace(void* device_mem, int cap, int K) { return carve(static_cast<char*>(device_mem), cap, K, nullptr); }
 
 int enqueue_pursuit(const DictDevice& dict, const Workspace& ws, const FrameInput& in, const Outputs& out,
-                    const double* quant_dev, int K, long long tc_begin, int n, int parts, int row_parts, void* stream_)
+                    const double* quant_dev, int K, long long tc_begin, int n, int parts, int row_parts, int sweep_waves,
+                    void* stream_)
 {
     hipStream_t s = static_cast<hipStream_t>(stream_);
     if (n < 1 || n > ws.cap) return (int)hipErrorInvalidValue;
@@ -645,32 +693,34 @@ int enqueue_pursuit(const DictDevice& dict, const Workspace& ws, const FrameInpu
     if (parts > kMaxParts) parts = kMaxParts;
     if (row_parts < 1) row_parts = 1;
     if (row_parts > kMaxRowParts) row_parts = kMaxRowParts;
-    // per-channel list capacity: n/3 units in tile mode (batches hold whole units), n in vector mode
+    // Persistent grids: every kernel strides over work whose amount is only known on the device (active
+    // counts shrink every step), so grid sizes are machine-sized, not problem-sized.
     const int per_list = in.vec_in ? n : (n + 2) / 3;
-    const unsigned groups = (unsigned)((per_list + 63) / 64);
-    const unsigned bpc = (unsigned)((per_list + 255) / 256);          // 256-thread blocks per channel
+    const unsigned lists = in.vec_in ? 1u : 3u;
+    const unsigned max_groups = lists * (unsigned)((per_list + 63) / 64);
+    const unsigned max_slabs = lists * (unsigned)((per_list + 255) / 256);
+    const unsigned slots = (unsigned)(sweep_waves > 0 ? sweep_waves : 3072);
     const unsigned blocks_n = (unsigned)((n + 255) / 256);
+    auto clampu = [](unsigned v, unsigned hi) { return v < hi ? (v ? v : 1u) : hi; };
     hipLaunchKernelGGL(mp_init_kernel, dim3(blocks_n), dim3(256), 0, s, ws, in, tc_begin, n);
     for (int step = 0; step < K; ++step) {
         const int cur = step & 1;
         if (step > 0) {
             hipLaunchKernelGGL(mp_bucket_kernel, dim3(1), dim3(1024), 0, s, ws, step & 1);
-            hipLaunchKernelGGL(mp_fill_kernel, dim3(3u * bpc), dim3(256), 0, s, ws, cur, (int)bpc);
+            hipLaunchKernelGGL(mp_fill_kernel, dim3(clampu(max_slabs, 2048u)), dim3(256), 0, s, ws, cur);
         }
-        hipLaunchKernelGGL(mp_base_kernel, dim3(3u * groups * (unsigned)parts), dim3(64), 0, s, ws, dict, cur, (int)groups,
+        hipLaunchKernelGGL(mp_base_kernel, dim3(clampu(max_groups * (unsigned)parts, slots)), dim3(64), 0, s, ws, dict, cur,
                            parts);
         if (step > 0) {
-            hipLaunchKernelGGL(mp_detail0_kernel, dim3(3u * groups * (unsigned)row_parts), dim3(64), 0, s, ws, dict, cur,
-                               (int)groups, row_parts);
-            unsigned dwaves = 3u * groups * (unsigned)row_parts;
-            if (dwaves > 6144u) dwaves = 6144u;
-            if (dwaves < 64u) dwaves = 64u;
-            hipLaunchKernelGGL(mp_detail_kernel, dim3(dwaves), dim3(64), 0, s, ws, dict, row_parts, ws.cand_val);
+            hipLaunchKernelGGL(mp_detail0_kernel, dim3(clampu(max_groups * (unsigned)row_parts, slots)), dim3(64), 0, s, ws,
+                               dict, cur, row_parts);
+            hipLaunchKernelGGL(mp_detail_kernel, dim3(clampu(max_groups * (unsigned)row_parts, slots)), dim3(64), 0, s, ws,
+                               dict, row_parts, ws.cand_val);
         }
-        hipLaunchKernelGGL(mp_finish_kernel, dim3(3u * bpc), dim3(256), 0, s, ws, dict, out, quant_dev, K, step, cur, parts,
-                           row_parts, (int)bpc);
+        hipLaunchKernelGGL(mp_finish_kernel, dim3(clampu(max_slabs, 2048u)), dim3(256), 0, s, ws, dict, out, quant_dev, K,
+                           step, cur, parts, row_parts);
         if (step + 1 < K)
-            hipLaunchKernelGGL(mp_update_kernel, dim3(3u * groups), dim3(64), 0, s, ws, dict, cur, (int)groups);
+            hipLaunchKernelGGL(mp_update_kernel, dim3(clampu(max_groups, 4096u)), dim3(64), 0, s, ws, dict, cur);
     }
     return (int)hipGetLastError();
 }

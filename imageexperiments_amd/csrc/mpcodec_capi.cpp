@@ -98,31 +98,10 @@ mpc_status ensure_workspace(mpc_context* c, long long tile_channels) {
     return MPC_OK;
 }
 
-// Split the 510 base atoms over `parts` waves per 64 tile-channels so that a step's grid is a whole number of
-// full machine fills (3 waves per SIMD): minimises ceil(waves / slots) * (510 / parts), smallest parts on ties.
-int pick_parts(const mpc_context* c, long long n, bool vector_mode) {
-    const long long per_list = vector_mode ? n : (n + 2) / 3;
-    const long long groups = (vector_mode ? 1 : 3) * ((per_list + 63) / 64);
-    const long long slots = 12LL * (c->num_cus > 0 ? c->num_cus : 256);
-    int best = 1;
-    double best_cost = 1e300;
-    for (int p = 1; p <= mpc::kMaxParts; ++p) {
-        const double rounds = static_cast<double>((groups * p + slots - 1) / slots);
-        const double cost = rounds * (510.0 / p + 8.0);          // + fixed per-wave cost (residual load, launch)
-        if (cost < best_cost - 1e-9) { best_cost = cost; best = p; }
-    }
-    return best;
-}
-
-// Small batches do not have enough (bucket, chunk) units to fill the machine: split each block's rows too.
-int pick_row_parts(const mpc_context* c, long long n, bool vector_mode) {
-    const long long per_list = vector_mode ? n : (n + 2) / 3;
-    const long long groups = (vector_mode ? 1 : 3) * ((per_list + 63) / 64);
-    const long long slots = 12LL * (c->num_cus > 0 ? c->num_cus : 256);
-    if (groups >= 2 * slots) return 1;
-    if (groups >= slots) return 2;
-    return mpc::kMaxRowParts;
-}
+// Sweep work is cut fine (8 atom ranges per 64 tile-channels, 4 row ranges per detail block) and handed to
+// machine-sized persistent grids, so a step's last round is nearly full whatever the active count is.
+constexpr int kBaseParts = 8;
+constexpr int kRowParts = 4;
 
 mpc_status run_pursuit(mpc_context* c, const mpc::FrameInput& in, const mpc::Outputs& out, const double* d_quant,
                        long long total_tc, void* stream) {
@@ -132,8 +111,7 @@ mpc_status run_pursuit(mpc_context* c, const mpc::FrameInput& in, const mpc::Out
     for (long long begin = 0; begin < total_tc; begin += c->ws_cap) {
         const long long n = (total_tc - begin < c->ws_cap) ? total_tc - begin : c->ws_cap;
         const int err = mpc::enqueue_pursuit(dict, c->ws, in, out, d_quant, c->K, begin, static_cast<int>(n),
-                                             pick_parts(c, n, in.vec_in != nullptr),
-                                             pick_row_parts(c, n, in.vec_in != nullptr), stream);
+                                             kBaseParts, kRowParts, c->max_waves, stream);
         if (err != 0) return fail(MPC_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(err)));
     }
     return MPC_OK;
