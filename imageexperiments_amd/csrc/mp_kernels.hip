@@ -369,27 +369,52 @@ __global__ __launch_bounds__(1024) void mp_bucket_kernel(const Workspace ws, int
 }
 
 // fill: each active tile-channel drops one item per unlocked, non-repeated block (block 0 excepted) into
-// that block's bucket and remembers the slot.
+// that block's bucket and remembers the slot.  A slab of 256 list entries (one channel) first ranks its items
+// per block in LDS, reserves one range per touched bucket with a single global atomic, then scatters: popular
+// blocks would otherwise serialise tens of thousands of same-address atomics per step.
 __global__ __launch_bounds__(256) void mp_fill_kernel(const Workspace ws, int cur)
 {
-    // grid-stride over 256-entry slabs of the three active lists
+    __shared__ unsigned s_cnt[512];
+    __shared__ unsigned s_base[512];
     const int s0 = ((int)ws.counters[cur * 3 + 0] + 255) >> 8, s1 = ((int)ws.counters[cur * 3 + 1] + 255) >> 8,
               s2 = ((int)ws.counters[cur * 3 + 2] + 255) >> 8;
+    for (int b = threadIdx.x; b < 512; b += 256) s_cnt[b] = 0;
+    __syncthreads();
     for (int slab = blockIdx.x; slab < s0 + s1 + s2; slab += gridDim.x) {
-    const int ch = slab < s0 ? 0 : (slab < s0 + s1 ? 1 : 2);
-    const int n_act = (int)ws.counters[cur * 3 + ch];
-    const int pos = (slab - (ch == 0 ? 0 : (ch == 1 ? s0 : s0 + s1))) * 256 + (int)threadIdx.x;
-    if (pos >= n_act) continue;
-    const int tc = ws.act[cur][ch][pos];
-    const int nb = ws.nblk[tc];
-    for (int i = 0; i < nb; ++i) {
-        const unsigned e = ws.blk_list[(long long)tc * kMaxDeviceK + i];
-        if (e == 0 || (e & 0x8000u)) continue;
-        const int b = (ch << 9) | (int)e;
-        const unsigned slot = ws.bucket_start[b] + atomicAdd(&ws.bucket_cursor[b], 1u);
-        ws.items[slot] = tc;
-        ws.item_slot[(long long)tc * kMaxDeviceK + i] = (int)slot;
-    }
+        const int ch = slab < s0 ? 0 : (slab < s0 + s1 ? 1 : 2);
+        const int n_act = (int)ws.counters[cur * 3 + ch];
+        const int pos = (slab - (ch == 0 ? 0 : (ch == 1 ? s0 : s0 + s1))) * 256 + (int)threadIdx.x;
+        const bool valid = pos < n_act;
+        int tc = 0, nb = 0;
+        if (valid) {
+            tc = ws.act[cur][ch][pos];
+            nb = ws.nblk[tc];
+            for (int i = 0; i < nb; ++i) {
+                const unsigned e = ws.blk_list[(long long)tc * kMaxDeviceK + i];
+                if (e == 0 || (e & 0x8000u)) continue;
+                ws.item_slot[(long long)tc * kMaxDeviceK + i] = (int)atomicAdd(&s_cnt[e], 1u);   // rank within the slab
+            }
+        }
+        __syncthreads();
+        for (int b = threadIdx.x; b < 512; b += 256) {
+            const unsigned c = s_cnt[b];
+            if (c) {
+                const int gb = (ch << 9) | b;
+                s_base[b] = ws.bucket_start[gb] + atomicAdd(&ws.bucket_cursor[gb], c);
+                s_cnt[b] = 0;
+            }
+        }
+        __syncthreads();
+        if (valid) {
+            for (int i = 0; i < nb; ++i) {
+                const unsigned e = ws.blk_list[(long long)tc * kMaxDeviceK + i];
+                if (e == 0 || (e & 0x8000u)) continue;
+                const unsigned slot = s_base[e] + (unsigned)ws.item_slot[(long long)tc * kMaxDeviceK + i];
+                ws.items[slot] = tc;
+                ws.item_slot[(long long)tc * kMaxDeviceK + i] = (int)slot;
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -404,11 +429,14 @@ __global__ __launch_bounds__(256) void mp_finish_kernel(const Workspace ws, cons
 {
     const int s0 = ((int)ws.counters[cur * 3 + 0] + 255) >> 8, s1 = ((int)ws.counters[cur * 3 + 1] + 255) >> 8,
               s2 = ((int)ws.counters[cur * 3 + 2] + 255) >> 8;
+    __shared__ unsigned s_cnt[512];          // next step's items per block, counted per slab before going global
+    for (int b = threadIdx.x; b < 512; b += 256) s_cnt[b] = 0;
+    __syncthreads();
     for (int slab = blockIdx.x; slab < s0 + s1 + s2; slab += gridDim.x) {
     const int ch = slab < s0 ? 0 : (slab < s0 + s1 ? 1 : 2);
     const int n_act = (int)ws.counters[cur * 3 + ch];
     const int pos = (slab - (ch == 0 ? 0 : (ch == 1 ? s0 : s0 + s1))) * 256 + (int)threadIdx.x;
-    if (pos >= n_act) continue;
+    if (pos < n_act) {
     const int tc = ws.act[cur][ch][pos];
     const unsigned oi = (unsigned)ws.out_index[tc];
     const long long rec = (long long)(oi & 0x3FFFFFFFu);
@@ -512,16 +540,26 @@ __global__ __launch_bounds__(256) void mp_finish_kernel(const Workspace ws, cons
         const unsigned slot = first + (unsigned)__popcll(going & ((1ULL << (threadIdx.x & 63)) - 1ULL));
         ws.act[cur ^ 1][ch][slot] = tc;
         // items of the next step: every unlocked, non-repeated block except block 0
-        unsigned* cnt = ws.bucket_count[(step + 1) & 1];
         const int nb2 = nb + (unlocked ? 1 : 0);
         for (int i = 0; i < nb2; ++i) {
             const unsigned e = ws.blk_list[(long long)tc * kMaxDeviceK + i];
             if (e == 0 || (e & 0x8000u)) continue;
-            atomicAdd(&cnt[(ch << 9) | (int)e], 1u);
+            atomicAdd(&s_cnt[e], 1u);
         }
     }
     }
+    __syncthreads();
+    {
+        unsigned* cnt = ws.bucket_count[(step + 1) & 1];
+        for (int b = threadIdx.x; b < 512; b += 256) {
+            const unsigned c = s_cnt[b];
+            if (c) { atomicAdd(&cnt[(ch << 9) | b], c); s_cnt[b] = 0; }
+        }
+    }
+    __syncthreads();
+    }
 }
+
 
 // update: r -= coeff * atom for every tile-channel the finish kernel quantised to a non-zero coefficient
 // (Vector::Scale then Vector::Subtract, mathvector.cpp:116-148: two roundings).  One wave per 64 entries of
