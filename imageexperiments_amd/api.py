@@ -76,10 +76,8 @@ def load_library():
 
 
 def _bind_bitstream(L):
-    """Entry points of the host entropy stage (present once host_bitstream.cpp is part of the build)."""
+    """Entry points of the host entropy stage / container."""
     vp = C.c_void_p
-    if not hasattr(L, "mpc_write_compressed"):
-        return
     L.mpc_free.argtypes = [vp]
     L.mpc_write_compressed.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _dp, _u16p, C.c_size_t,
                                        C.POINTER(_u16p), C.POINTER(C.c_size_t), C.POINTER(_u8p), C.POINTER(C.c_size_t)]
@@ -96,9 +94,131 @@ def _bind_bitstream(L):
     L.mpc_huffman_decode.argtypes = [_u8p, C.c_size_t, C.POINTER(_u16p), C.POINTER(C.c_size_t)]
     L.mpc_rle_encode.argtypes = [_u16p, C.c_size_t, C.POINTER(_u16p), C.POINTER(C.c_size_t)]
     L.mpc_rle_decode.argtypes = [_u16p, C.c_size_t, C.POINTER(_u16p), C.POINTER(C.c_size_t)]
+    L.mpc_encode_image.argtypes = [vp, _u8p, C.c_int, C.c_int, _dp, C.POINTER(_u8p), C.POINTER(C.c_size_t)]
     L.mpc_decode_image.argtypes = [vp, _u8p, C.c_size_t, C.POINTER(_u8p), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.mpc_psnr.argtypes = [_u8p, _u8p, C.c_int, C.c_int]
     L.mpc_psnr.restype = C.c_double
+
+
+def _take_bytes(L, p, n):
+    out = C.string_at(p, n.value)
+    L.mpc_free(C.cast(p, C.c_void_p))
+    return out
+
+
+def _take_u16(L, p, n):
+    out = np.ctypeslib.as_array(p, shape=(n.value,)).copy() if n.value else np.zeros(0, np.uint16)
+    L.mpc_free(C.cast(p, C.c_void_p))
+    return out
+
+
+def _u16(a):
+    a = np.ascontiguousarray(a, np.uint16)
+    return a, a.ctypes.data_as(_u16p)
+
+
+# -- host entropy stage (huffman:: / compressed:: free functions of the reference) -----------------------------
+def huffman_encode(data):
+    """huffman::huffmanEncode (Huffman.h:15) -> bytes."""
+    L = load_library()
+    a, p = _u16(data)
+    out, n = _u8p(), C.c_size_t(0)
+    _check(L.mpc_huffman_encode(p, a.size, C.byref(out), C.byref(n)))
+    return _take_bytes(L, out, n)
+
+
+def huffman_decode(blob):
+    """huffman::huffmanDecode (Huffman.h:18) -> uint16 array; raises MpcError(MPC_ERR_BITSTREAM) on invalid data."""
+    L = load_library()
+    buf = np.frombuffer(bytes(blob), np.uint8)
+    out, n = _u16p(), C.c_size_t(0)
+    _check(L.mpc_huffman_decode(buf.ctypes.data_as(_u8p), buf.size, C.byref(out), C.byref(n)))
+    return _take_u16(L, out, n)
+
+
+def run_length_encode(data):
+    L = load_library()
+    a, p = _u16(data)
+    out, n = _u16p(), C.c_size_t(0)
+    _check(L.mpc_rle_encode(p, a.size, C.byref(out), C.byref(n)))
+    return _take_u16(L, out, n)
+
+
+def run_length_decode(data):
+    L = load_library()
+    a, p = _u16(data)
+    out, n = _u16p(), C.c_size_t(0)
+    _check(L.mpc_rle_decode(p, a.size, C.byref(out), C.byref(n)))
+    return _take_u16(L, out, n)
+
+
+def write_compressed(width, height, K, block_size, quant, lengths, codes):
+    """compressed::writeCompressed (CompressedImage.cpp:403): codes = 6K uint16 arrays, DC not yet differenced."""
+    L = load_library()
+    q = np.ascontiguousarray(quant, np.float64).reshape(3 * K)
+    ln, lp = _u16(lengths)
+    arrs = [np.ascontiguousarray(c, np.uint16) for c in codes]
+    ptrs = (_u16p * (6 * K))(*[a.ctypes.data_as(_u16p) for a in arrs])
+    sizes = (C.c_size_t * (6 * K))(*[a.size for a in arrs])
+    out, n = _u8p(), C.c_size_t(0)
+    _check(L.mpc_write_compressed(width, height, K, block_size, q.ctypes.data_as(_dp), lp, ln.size, ptrs, sizes,
+                                  C.byref(out), C.byref(n)))
+    return _take_bytes(L, out, n)
+
+
+def assemble_streams(width, height, K, block_size, quant, counts, choices):
+    """Host half of encodeImage: whole-frame records (tile t = tx*tiles_y + ty) -> container bytes."""
+    L = load_library()
+    q = np.ascontiguousarray(quant, np.float64).reshape(3 * K)
+    cn, cp = _u16(counts)
+    ch = np.ascontiguousarray(choices)
+    out, n = _u8p(), C.c_size_t(0)
+    _check(L.mpc_assemble_streams(width, height, K, block_size, q.ctypes.data_as(_dp), cp, ch.ctypes.data_as(C.c_void_p),
+                                  C.byref(out), C.byref(n)))
+    return _take_bytes(L, out, n)
+
+
+def read_compressed(blob):
+    """compressed::readCompressed (CompressedImage.cpp:635) -> dict(W,H,K,bs,quant[3,K],lengths,codes[6K])."""
+    L = load_library()
+    buf = np.frombuffer(bytes(blob), np.uint8)
+    h = C.c_void_p()
+    _check(L.mpc_read_compressed(buf.ctypes.data_as(_u8p), buf.size, C.byref(h)))
+    try:
+        W, H, K, bs = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        _check(L.mpc_streams_info(h, C.byref(W), C.byref(H), C.byref(K), C.byref(bs)))
+        quant = np.zeros((3, K.value), np.uint16)
+        _check(L.mpc_streams_quant(h, quant.ctypes.data_as(_u16p)))
+
+        def stream(i):
+            a = np.zeros(L.mpc_streams_length(h, i), np.uint16)
+            if a.size:
+                _check(L.mpc_streams_copy(h, i, a.ctypes.data_as(_u16p)))
+            return a
+        return dict(W=W.value, H=H.value, K=K.value, bs=bs.value, quant=quant, lengths=stream(-1),
+                    codes=[stream(i) for i in range(6 * K.value)])
+    finally:
+        L.mpc_streams_free(h)
+
+
+def decode_image(blob, ctx=None):
+    """compressed::decodeImage (CompressedImage.h:75) -> uint8 [H,W,3]."""
+    L = load_library()
+    buf = np.frombuffer(bytes(blob), np.uint8)
+    out, W, H = _u8p(), C.c_int(), C.c_int()
+    _check(L.mpc_decode_image(ctx.h if ctx is not None else None, buf.ctypes.data_as(_u8p), buf.size, C.byref(out),
+                              C.byref(W), C.byref(H)))
+    img = np.ctypeslib.as_array(out, shape=(H.value, W.value, 3)).copy()
+    L.mpc_free(C.cast(out, C.c_void_p))
+    return img
+
+
+def calculate_psnr(original, decoded):
+    """compressed::calculatePSNR (CompressedImage.h:57)."""
+    L = load_library()
+    a = np.ascontiguousarray(original, np.uint8)
+    b = np.ascontiguousarray(decoded, np.uint8)
+    return L.mpc_psnr(a.ctypes.data_as(_u8p), b.ctypes.data_as(_u8p), a.shape[1], a.shape[0])
 
 
 def _check(st):
@@ -212,6 +332,18 @@ class CompressionContext:
     def reserve(self, max_tiles):
         """Pre-allocate the device workspace for calls of up to `max_tiles` tiles."""
         _check(self.L.mpc_reserve(self.h, int(max_tiles)))
+
+    def encode_image(self, rgb, quant=None):
+        """compressed::encodeImage (CompressedImage.h:59): device tile encode + host entropy stage -> bytes."""
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        H, W = rgb.shape[:2]
+        qp = None
+        if quant is not None:
+            quant = np.ascontiguousarray(quant, np.float64).reshape(3, self.K)
+            qp = quant.ctypes.data_as(_dp)
+        out, n = _u8p(), C.c_size_t(0)
+        _check(self.L.mpc_encode_image(self.h, rgb.ctypes.data_as(_u8p), W, H, qp, C.byref(out), C.byref(n)))
+        return _take_bytes(self.L, out, n)
 
     def calc_mp(self, channel, vectors, quant_k=None):
         """matching::CalcMPDynamic (MatchingPursuit.h:22) on the device for vectors[n,64].

@@ -1,0 +1,600 @@
+// host_bitstream.cpp -- product host code: entropy stage + container (see host_bitstream.h).
+#include "host_bitstream.h"
+
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+
+namespace mpc {
+
+// ------------------------------------------------------------------------------------------------
+// bits
+// ------------------------------------------------------------------------------------------------
+void BitWriter::put(uint64_t value, int width) {
+    if (width <= 0) return;
+    if (width < 64) value &= (1ULL << width) - 1ULL;
+    const size_t word = nbits_ >> 6;
+    const int used = static_cast<int>(nbits_ & 63);
+    if (words_.size() < word + 2) words_.resize(word + 2, 0);
+    const int room = 64 - used;
+    if (width <= room) {
+        words_[word] |= (width == 64) ? value : (value << (room - width));
+    } else {
+        words_[word] |= value >> (width - room);
+        words_[word + 1] = value << (64 - (width - room));
+    }
+    nbits_ += static_cast<size_t>(width);
+}
+
+void BitWriter::append(const BitWriter& other) {
+    const size_t full = other.nbits_ >> 6;
+    for (size_t i = 0; i < full; ++i) put(other.words_[i], 64);
+    const int tail = static_cast<int>(other.nbits_ & 63);
+    if (tail) put(other.words_[full] >> (64 - tail), tail);
+}
+
+std::vector<uint8_t> BitWriter::bytes() const {
+    const size_t n = (nbits_ + 7) / 8;
+    std::vector<uint8_t> out(n);
+    for (size_t i = 0; i < n; ++i) out[i] = static_cast<uint8_t>(words_[i >> 3] >> (56 - 8 * (i & 7)));
+    return out;
+}
+
+uint64_t BitReader::get(int width) {
+    if (width <= 0) return 0;
+    const size_t left = nbits_ - pos_;
+    if (static_cast<size_t>(width) > left) width = static_cast<int>(left);
+    uint64_t v = 0;
+    int need = width;
+    while (need > 0) {
+        const size_t byte = pos_ >> 3;
+        const int off = static_cast<int>(pos_ & 7);
+        const int take = std::min(need, 8 - off);
+        const uint32_t bits = (static_cast<uint32_t>(p_[byte]) >> (8 - off - take)) & ((1u << take) - 1u);
+        v = (v << take) | bits;
+        pos_ += static_cast<size_t>(take);
+        need -= take;
+    }
+    return v;
+}
+
+namespace {
+
+inline uint32_t bit_width(uint32_t v) { return v ? 32u - static_cast<uint32_t>(__builtin_clz(v)) : 0u; }
+
+}  // namespace
+
+// BitBuffer.cpp:228-269 (the reference's own Golomb variant: remainder in bit_width(M) bits)
+uint32_t golomb_length(uint32_t value, uint32_t m) {
+    const uint32_t q = static_cast<uint32_t>(static_cast<int32_t>(value) / static_cast<int32_t>(m));
+    const uint32_t rem = static_cast<uint32_t>(static_cast<int32_t>(value) % static_cast<int32_t>(m));
+    const uint32_t b = bit_width(m);
+    const uint32_t limit = (1u << (b + 1)) - m;
+    return (rem < limit) ? b + q + 1 : b + q + 2;
+}
+
+void golomb_write(uint32_t value, uint32_t m, BitWriter& out) {
+    uint32_t q = static_cast<uint32_t>(static_cast<int32_t>(value) / static_cast<int32_t>(m));
+    const uint32_t rem = static_cast<uint32_t>(static_cast<int32_t>(value) % static_cast<int32_t>(m));
+    while (q >= 64) { out.put(~0ULL, 64); q -= 64; }
+    if (q) out.put((1ULL << q) - 1ULL, static_cast<int>(q));
+    out.put(0, 1);
+    const uint32_t b = bit_width(m);
+    const uint32_t limit = (1u << (b + 1)) - m;
+    if (rem < limit) out.put(rem, static_cast<int>(b));
+    else out.put(static_cast<uint64_t>(rem) + limit, static_cast<int>(b) + 1);
+}
+
+uint32_t golomb_read(uint32_t m, BitReader& in) {
+    uint32_t q = 0;
+    while (in.get(1) != 0) {
+        ++q;
+        if (in.remaining() == 0) break;
+    }
+    const uint32_t b = bit_width(m);
+    const uint32_t limit = (1u << (b + 1)) - m;
+    const uint32_t first = static_cast<uint32_t>(in.get(static_cast<int>(b)));
+    const uint32_t rem = (first < limit) ? first : (first << 1) + static_cast<uint32_t>(in.get(1)) - limit;
+    return q * m + rem;
+}
+
+namespace {
+
+// Elias-Fano coding of a non-decreasing u16 sequence (BitBuffer.cpp:292-354)
+uint32_t elias_fano_length(size_t n, uint16_t max_symbol) {
+    if (n == 0) return 0;
+    const uint32_t m = bit_width(max_symbol), nb = bit_width(static_cast<uint32_t>(n));
+    const uint32_t low = (m >= nb) ? m - nb : 0;
+    return static_cast<uint32_t>(n) * (1 + low) + (1u << (m - low)) - 1;
+}
+
+void elias_fano_write(const uint16_t* seq, size_t n, uint16_t max_symbol, BitWriter& out) {
+    if (n == 0) return;
+    const uint32_t m = bit_width(max_symbol), nb = bit_width(static_cast<uint32_t>(n));
+    const uint32_t low = (m >= nb) ? m - nb : 0;
+    uint32_t bucket = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const uint16_t target = static_cast<uint16_t>(seq[i] >> low);
+        while (bucket != target) { out.put(0, 1); ++bucket; }
+        out.put(1, 1);
+    }
+    for (size_t i = 0; i < n; ++i) out.put(seq[i], static_cast<int>(low));
+}
+
+bool elias_fano_read(uint16_t* dst, size_t n, uint16_t max_symbol, BitReader& in) {
+    if (n == 0) return true;
+    const uint32_t m = bit_width(max_symbol), nb = bit_width(static_cast<uint32_t>(n));
+    const uint32_t low = (m >= nb) ? m - nb : 0;
+    uint16_t bucket = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (in.remaining() == 0) return false;
+        while (in.get(1) == 0) {
+            ++bucket;
+            if (in.remaining() == 0) return false;
+        }
+        dst[i] = static_cast<uint16_t>(bucket << low);
+    }
+    for (size_t i = 0; i < n; ++i) dst[i] |= static_cast<uint16_t>(in.get(static_cast<int>(low)));
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Iteration order of MSVC's std::unordered_map<uint32_t, T> after a given insertion sequence.
+//
+// huffmanEncode pushes its leaves into the priority queue while iterating such a map (Huffman.cpp:47,
+// 72-81), so equal-frequency ties -- and with them code lengths and bytes -- follow that order.  The
+// reference builds only with Visual Studio 2022; its STL keeps all elements in one doubly linked list plus
+// [first,last] iterators per bucket (bucket = FNV-1a(key) & (buckets-1); 8 buckets, load factor 1, growth
+// x8 below 512 buckets and to the next power of two >= size afterwards).  A key whose bucket is empty is
+// linked at the end of the list, otherwise directly in front of its bucket's first element; a rehash walks
+// the list in order applying the same rule.  Iteration = list order.
+// ------------------------------------------------------------------------------------------------
+class MsvcHashOrder {
+public:
+    MsvcHashOrder() : first_(8, kNone), last_(8, kNone) {
+        next_.push_back(0);
+        prev_.push_back(0);
+        keys_.push_back(0);
+    }
+    // insert a key known to be absent; returns its node id (1-based, in insertion order)
+    int insert(uint32_t key) {
+        const int node = static_cast<int>(keys_.size());
+        keys_.push_back(key);
+        next_.push_back(0);
+        prev_.push_back(0);
+        if (size_ + 1 > first_.size()) grow(size_ + 1);
+        place(node);
+        ++size_;
+        return node;
+    }
+    template <class F>
+    void for_each(F&& f) const {
+        for (int n = next_[0]; n != 0; n = next_[n]) f(n);
+    }
+
+private:
+    static constexpr int kNone = 0;      // node 0 is the list head, i.e. end()
+    static uint64_t fnv1a(uint32_t key) {
+        uint64_t h = 14695981039346656037ULL;
+        for (int i = 0; i < 4; ++i) {
+            h ^= (key >> (8 * i)) & 0xFFu;
+            h *= 1099511628211ULL;
+        }
+        return h;
+    }
+    size_t bucket_of(uint32_t key) const { return static_cast<size_t>(fnv1a(key)) & (first_.size() - 1); }
+    void link_before(int node, int where) {
+        const int before = prev_[where];
+        next_[node] = where;
+        prev_[node] = before;
+        next_[before] = node;
+        prev_[where] = node;
+    }
+    void unlink(int node) {
+        next_[prev_[node]] = next_[node];
+        prev_[next_[node]] = prev_[node];
+    }
+    void place(int node) {                      // node not linked yet
+        const size_t b = bucket_of(keys_[node]);
+        if (first_[b] == kNone) {
+            link_before(node, 0);
+            first_[b] = last_[b] = node;
+        } else {
+            link_before(node, first_[b]);
+            first_[b] = node;
+        }
+    }
+    void grow(size_t for_size) {
+        size_t want = first_.size() < 512 && first_.size() * 8 >= for_size ? first_.size() * 8 : for_size;
+        size_t buckets = 1;
+        while (buckets < want) buckets <<= 1;
+        first_.assign(buckets, kNone);
+        last_.assign(buckets, kNone);
+        int node = next_[0];
+        while (node != 0) {
+            const int following = next_[node];
+            const size_t b = bucket_of(keys_[node]);
+            if (first_[b] == kNone) {
+                first_[b] = last_[b] = node;            // stays where it is
+            } else {
+                unlink(node);
+                link_before(node, first_[b]);
+                first_[b] = node;
+            }
+            node = following;
+        }
+    }
+    std::vector<uint32_t> keys_;
+    std::vector<int> next_, prev_, first_, last_;
+    size_t size_ = 0;
+};
+
+constexpr uint32_t kPseudoEof = 0xFFFFFFFFu;
+
+struct HeapNode {
+    size_t freq;
+    uint8_t depth;
+    int id;                       // index into the parent[] forest
+};
+struct HeapAfter {                // NodeCompare (Huffman.cpp:21-25)
+    bool operator()(const HeapNode& a, const HeapNode& b) const { return a.freq > b.freq; }
+};
+
+struct Entry {
+    uint32_t symbol;
+    uint8_t length;
+    uint32_t code;
+};
+
+}  // namespace
+
+// Huffman.cpp:46-163
+void huffman_encode(const uint16_t* data, size_t n, BitWriter& out) {
+    std::vector<int> leaf_of(65536, -1);
+    std::vector<uint32_t> symbols;
+    std::vector<size_t> freq;
+    MsvcHashOrder order;
+    uint8_t symbol_bits = 1;
+    for (size_t i = 0; i < n; ++i) {
+        const uint32_t s = data[i];
+        symbol_bits = std::max<uint8_t>(symbol_bits, static_cast<uint8_t>(bit_width(s)));
+        int& leaf = leaf_of[s];
+        if (leaf < 0) {
+            leaf = static_cast<int>(symbols.size());
+            symbols.push_back(s);
+            freq.push_back(0);
+            order.insert(s);                                   // node id == leaf + 1
+        }
+        ++freq[leaf];
+    }
+    const int eof_leaf = static_cast<int>(symbols.size());
+    symbols.push_back(kPseudoEof);
+    freq.push_back(0);
+    order.insert(kPseudoEof);
+    const int leaves = static_cast<int>(symbols.size());
+
+    // tree: leaves 0..leaves-1, internal nodes appended; code length = depth below the root
+    std::vector<int> parent(static_cast<size_t>(2 * leaves), -1);
+    std::vector<HeapNode> heap;
+    heap.reserve(static_cast<size_t>(leaves));
+    order.for_each([&](int node) {
+        heap.push_back(HeapNode{freq[node - 1], 0, node - 1});
+        std::push_heap(heap.begin(), heap.end(), HeapAfter());
+    });
+    int next_id = leaves;
+    while (heap.size() > 1) {
+        std::pop_heap(heap.begin(), heap.end(), HeapAfter());
+        const HeapNode a = heap.back();
+        heap.pop_back();
+        std::pop_heap(heap.begin(), heap.end(), HeapAfter());
+        const HeapNode b = heap.back();
+        heap.pop_back();
+        parent[a.id] = next_id;
+        parent[b.id] = next_id;
+        heap.push_back(HeapNode{a.freq + b.freq, static_cast<uint8_t>(std::max(a.depth, b.depth) + 1), next_id});
+        std::push_heap(heap.begin(), heap.end(), HeapAfter());
+        ++next_id;
+    }
+    std::vector<Entry> entries(static_cast<size_t>(leaves));
+    for (int l = 0; l < leaves; ++l) {
+        uint8_t len = (n == 0 && l == eof_leaf) ? 1 : 0;       // :70 the lone pseudo-EOF gets length 1
+        for (int p = parent[l]; p >= 0; p = parent[p]) ++len;
+        entries[l] = Entry{symbols[l], len, 0};
+    }
+    std::sort(entries.begin(), entries.end(), [](const Entry& a, const Entry& b) {   // CanonicalSorter :27-35
+        return a.length == b.length ? a.symbol < b.symbol : a.length < b.length;
+    });
+    const uint8_t max_length = std::max<uint8_t>(heap.front().depth, 1);
+    out.put(max_length, 8);
+    std::vector<uint16_t> group_sizes;
+    std::vector<uint32_t> code_of(65536, 0);
+    std::vector<uint8_t> length_of(65536, 0);
+    uint32_t eof_code = 0;
+    uint8_t eof_length = 0;
+    uint8_t prev_length = 0;
+    uint32_t code = 0, count = 0;
+    for (Entry& e : entries) {
+        if (e.length != prev_length) {
+            if (prev_length != 0) {
+                out.put(static_cast<uint16_t>(count), 16);
+                group_sizes.push_back(static_cast<uint16_t>(count));
+            }
+            for (uint8_t l = static_cast<uint8_t>(prev_length + 1); l < e.length; ++l) {
+                out.put(0, 16);
+                group_sizes.push_back(0);
+            }
+            count = 0;
+            code <<= (e.length - prev_length);
+        }
+        e.code = code++;
+        ++count;
+        prev_length = e.length;
+        if (e.symbol == kPseudoEof) { eof_code = e.code; eof_length = e.length; }
+        else { code_of[e.symbol] = e.code; length_of[e.symbol] = e.length; }
+    }
+    out.put(static_cast<uint16_t>(count), 16);
+    group_sizes.push_back(static_cast<uint16_t>(count));
+    out.put(symbol_bits, 8);
+    const uint16_t mask = static_cast<uint16_t>((1u << symbol_bits) - 1u);
+    size_t at = 0;
+    std::vector<uint16_t> group;
+    for (size_t g = 0; at < entries.size(); ++g) {
+        const uint16_t size = group_sizes[g];
+        group.resize(size);
+        for (uint16_t k = 0; k < size; ++k) group[k] = static_cast<uint16_t>(entries[at + k].symbol) & mask;
+        if (elias_fano_length(size, mask) < static_cast<uint32_t>(size) * symbol_bits) elias_fano_write(group.data(), size, mask, out);
+        else for (uint16_t v : group) out.put(v, symbol_bits);
+        at += size;
+    }
+    for (size_t i = 0; i < n; ++i) out.put(code_of[data[i]], length_of[data[i]]);
+    out.put(eof_code, eof_length);
+}
+
+// Huffman.cpp:173-244
+bool huffman_decode(BitReader& in, std::vector<uint16_t>& out) {
+    const int max_length = static_cast<int>(in.get(8));
+    std::vector<uint16_t> counts(static_cast<size_t>(max_length));
+    uint16_t total = 0;
+    for (int l = 0; l < max_length; ++l) {
+        counts[l] = static_cast<uint16_t>(in.get(16));
+        total = static_cast<uint16_t>(total + counts[l]);
+    }
+    const int symbol_bits = static_cast<int>(in.get(8));
+    const uint16_t mask = static_cast<uint16_t>((1u << symbol_bits) - 1u);
+    std::vector<uint16_t> table(total);
+    size_t at = 0;
+    for (int l = 0; l < max_length; ++l) {
+        const uint16_t size = counts[l];
+        if (elias_fano_length(size, mask) < static_cast<uint32_t>(size) * static_cast<uint32_t>(symbol_bits)) {
+            if (!elias_fano_read(table.data() + at, size, mask, in)) return false;
+        } else {
+            for (uint16_t k = 0; k < size; ++k) table[at + k] = static_cast<uint16_t>(in.get(symbol_bits));
+        }
+        at += size;
+    }
+    if (total == 0 || table[total - 1u] != mask) return false;      // the last entry must be the pseudo-EOF
+    std::vector<uint32_t> first_code(static_cast<size_t>(max_length) + 1, 0), first_index(static_cast<size_t>(max_length) + 1, 0);
+    uint32_t code = 0, index = 0;
+    int prev = 0;
+    for (int l = 1; l <= max_length; ++l) {
+        if (!counts[l - 1]) continue;
+        code <<= (l - prev);
+        first_code[l] = code;
+        first_index[l] = index;
+        code += counts[l - 1];
+        index += counts[l - 1];
+        prev = l;
+    }
+    uint32_t acc = 0;
+    int bits = 0;
+    while (in.remaining() > 0) {
+        acc = (acc << 1) | static_cast<uint32_t>(in.get(1));
+        ++bits;
+        if (bits <= max_length && counts[bits - 1] && acc >= first_code[bits] && acc - first_code[bits] < counts[bits - 1]) {
+            const uint32_t entry = first_index[bits] + (acc - first_code[bits]);
+            if (entry == static_cast<uint32_t>(total) - 1u) return true;
+            out.push_back(table[entry]);
+            acc = 0;
+            bits = 0;
+        }
+    }
+    return false;
+}
+
+// Huffman.cpp:246-310
+std::vector<uint16_t> rle_encode(const uint16_t* data, size_t n) {
+    std::vector<uint16_t> out;
+    out.reserve(n);
+    uint16_t prev = 0, run = 0;
+    bool fresh = true;
+    for (size_t i = 0; i < n; ++i) {
+        const uint16_t v = data[i];
+        if (v == prev && !fresh) {
+            if (++run == 1) out.push_back(v);
+            else if (run >= 0x8000) { out.push_back(static_cast<uint16_t>(run - 1)); run = 0; fresh = true; }
+        } else {
+            fresh = false;
+            if (run > 0) { out.push_back(static_cast<uint16_t>(run - 1)); run = 0; }
+            prev = v;
+            out.push_back(v);
+        }
+    }
+    if (run > 0) out.push_back(static_cast<uint16_t>(run - 1));
+    return out;
+}
+
+std::vector<uint16_t> rle_decode(const uint16_t* data, size_t n) {
+    std::vector<uint16_t> out;
+    out.reserve(n);
+    uint16_t prev = 0;
+    bool expect_count = false, fresh = true;
+    for (size_t i = 0; i < n; ++i) {
+        const uint16_t v = data[i];
+        if (expect_count) {
+            out.insert(out.end(), v, prev);
+            expect_count = false;
+            fresh = true;
+        } else {
+            out.push_back(v);
+            if (v == prev && !fresh) expect_count = true;
+            fresh = false;
+            prev = v;
+        }
+    }
+    return out;
+}
+
+// CompressedImage.cpp:359-401.  The Golomb cost of each candidate M is the sum over DISTINCT symbols of
+// count x length -- same number as the reference's per-symbol loop.
+void write_huffman_or_golomb(const uint16_t* data, size_t n, BitWriter& out) {
+    BitWriter huff;
+    huffman_encode(data, n, huff);
+    size_t best = huff.bit_size();
+    int best_m = -1;
+    std::vector<uint32_t> hist(65536, 0);
+    std::vector<uint16_t> distinct;
+    for (size_t i = 0; i < n; ++i)
+        if (hist[data[i]]++ == 0) distinct.push_back(data[i]);
+    for (int m = 1; m < 2048; m = (m & 1) ? m + 1 : (m << 1) - 1) {
+        size_t estimate = 16;
+        for (uint16_t s : distinct) estimate += static_cast<size_t>(hist[s]) * golomb_length(s, static_cast<uint32_t>(m));
+        if (estimate < best) { best = estimate; best_m = m; }
+    }
+    if (best_m < 0) {
+        out.put(0, 1);
+        out.append(huff);
+    } else {
+        out.put(1, 1);
+        out.put(static_cast<uint16_t>(best_m), 16);
+        for (size_t i = 0; i < n; ++i) golomb_write(data[i], static_cast<uint32_t>(best_m), out);
+    }
+}
+
+bool read_huffman_or_golomb(BitReader& in, size_t length, std::vector<uint16_t>& out) {
+    if (in.get(1) == 0) return huffman_decode(in, out);
+    const uint32_t m = static_cast<uint32_t>(in.get(16));
+    if (m == 0) return false;
+    out.reserve(out.size() + length);
+    for (size_t i = 0; i < length; ++i) out.push_back(static_cast<uint16_t>(golomb_read(m, in)));
+    return true;
+}
+
+namespace {
+constexpr uint32_t kMagic = 0x4D4E3234u;        // CompressedImage.cpp:14
+
+std::vector<uint16_t> dc_difference(const std::vector<uint16_t>& v) {       // :428-446
+    std::vector<uint16_t> out(v.size());
+    int32_t prev = 0;
+    for (size_t i = 0; i < v.size(); ++i) {
+        out[i] = static_cast<uint16_t>(zigzag_encode(static_cast<int32_t>(v[i]) - prev));
+        prev = static_cast<int32_t>(v[i]);
+    }
+    return out;
+}
+}  // namespace
+
+std::vector<uint8_t> write_compressed(const Streams& s) {
+    const int K = s.K;
+    BitWriter out;
+    out.put(kMagic, 32);
+    out.put(static_cast<uint32_t>(s.width), 32);
+    out.put(static_cast<uint32_t>(s.height), 32);
+    out.put(static_cast<uint8_t>(K), 8);
+    out.put(static_cast<uint8_t>(s.block_size), 8);
+    for (int ch = 0; ch < 3; ++ch)
+        for (int i = 0; i < K; ++i) out.put(s.quant[ch][i], 16);
+    write_huffman_or_golomb(s.lengths.data(), s.lengths.size(), out);
+    for (int i = 0; i < 6 * K; ++i) {
+        const bool dc = (i == 1 || i == 2 * K + 1 || i == 4 * K + 1);
+        const std::vector<uint16_t> diffed = dc ? dc_difference(s.codes[i]) : std::vector<uint16_t>();
+        const std::vector<uint16_t>& stream = dc ? diffed : s.codes[i];
+        const std::vector<uint16_t> packed = rle_encode(stream.data(), stream.size());
+        if (packed.size() + 4 < stream.size()) {                 // :450
+            out.put(1, 1);
+            out.put(static_cast<uint32_t>(packed.size()), 32);
+            write_huffman_or_golomb(packed.data(), packed.size(), out);
+        } else {
+            out.put(0, 1);
+            write_huffman_or_golomb(stream.data(), stream.size(), out);
+        }
+    }
+    return out.bytes();
+}
+
+bool read_compressed(const uint8_t* bytes, size_t nbytes, Streams& s) {
+    BitReader in(bytes, nbytes);
+    if (static_cast<uint32_t>(in.get(32)) != kMagic) return false;
+    s.width = static_cast<int>(in.get(32));
+    s.height = static_cast<int>(in.get(32));
+    s.K = static_cast<int>(in.get(8));
+    s.block_size = static_cast<int>(in.get(8));
+    if (s.K < 1 || s.K > 32 || s.block_size < 1 || s.block_size > 8 || s.width < 1 || s.height < 1) return false;
+    const int K = s.K;
+    for (int ch = 0; ch < 3; ++ch)
+        for (int i = 0; i < K; ++i) s.quant[ch][i] = static_cast<uint16_t>(in.get(16));
+    const size_t tiles = static_cast<size_t>((s.width + s.block_size - 1) / s.block_size) *
+                         static_cast<size_t>((s.height + s.block_size - 1) / s.block_size);
+    s.lengths.clear();
+    if (!read_huffman_or_golomb(in, 3 * tiles, s.lengths)) return false;
+    s.codes.assign(static_cast<size_t>(6 * K), {});
+    for (int i = 0; i < 6 * K; ++i) {
+        if (in.get(1) == 1) {
+            const size_t packed_len = static_cast<size_t>(in.get(32));
+            std::vector<uint16_t> packed;
+            if (!read_huffman_or_golomb(in, packed_len, packed)) return false;
+            s.codes[i] = rle_decode(packed.data(), packed.size());
+        } else {
+            const size_t layer = static_cast<size_t>(i / 2) / K, depth = static_cast<size_t>(i / 2) % K;
+            size_t expect = 0;                                   // :680-685 length implied by `lengths`
+            for (size_t t = 0; t < s.lengths.size() / 3; ++t)
+                if (s.lengths[3 * t + layer] > depth) ++expect;
+            if (!read_huffman_or_golomb(in, expect, s.codes[i])) return false;
+        }
+    }
+    for (int idx : {1, 2 * K + 1, 4 * K + 1}) {                  // :690-705
+        int32_t acc = 0;
+        for (uint16_t& c : s.codes[idx]) {
+            acc += zigzag_decode(c);
+            c = static_cast<uint16_t>(acc);
+        }
+    }
+    return true;
+}
+
+Streams assemble_streams(int width, int height, int K, int block_size, const double* quant, const uint16_t* counts,
+                         const uint32_t* choices) {
+    Streams s;
+    s.width = width;
+    s.height = height;
+    s.K = K;
+    s.block_size = block_size;
+    for (int ch = 0; ch < 3; ++ch)
+        for (int i = 0; i < K; ++i) s.quant[ch][i] = static_cast<uint16_t>(quant[ch * K + i]);   // :420 u16 of an integral double
+    const size_t tiles = static_cast<size_t>((width + block_size - 1) / block_size) *
+                         static_cast<size_t>((height + block_size - 1) / block_size);
+    s.lengths.resize(3 * tiles);
+    s.codes.assign(static_cast<size_t>(6 * K), {});
+    // stream sizes first (one pass), then fill: no reallocation on multi-megabyte streams
+    std::vector<size_t> sizes(static_cast<size_t>(3 * K), 0);
+    for (size_t o = 0; o < 3 * tiles; ++o) {
+        s.lengths[o] = counts[o];
+        const int ch = static_cast<int>(o % 3);
+        for (int i = 0; i < counts[o]; ++i) ++sizes[static_cast<size_t>(ch * K + i)];
+    }
+    for (int ch = 0; ch < 3; ++ch)
+        for (int i = 0; i < K; ++i) {
+            s.codes[2 * K * ch + 2 * i].reserve(sizes[ch * K + i]);
+            s.codes[2 * K * ch + 2 * i + 1].reserve(sizes[ch * K + i]);
+        }
+    for (size_t o = 0; o < 3 * tiles; ++o) {
+        const int ch = static_cast<int>(o % 3);
+        const uint32_t* rec = choices + o * K;
+        for (int i = 0; i < counts[o]; ++i) {
+            s.codes[2 * K * ch + 2 * i].push_back(static_cast<uint16_t>(rec[i] & 0xFFFFu));
+            s.codes[2 * K * ch + 2 * i + 1].push_back(static_cast<uint16_t>(rec[i] >> 16));
+        }
+    }
+    return s;
+}
+
+}  // namespace mpc

@@ -1,0 +1,72 @@
+// host_bitstream.h -- product host code: the entropy stage and the ".mn" container of the
+// CompressionLib codec.  It stays on the host (BASELINE.json north_star) and must emit the
+// reference's bytes exactly:
+//   bit buffer, zigzag, Golomb, Elias-Fano     CompressionLib/src/BitBuffer.cpp, inc/BitBuffer.h
+//   canonical Huffman + u16 run-length code     CompressionLib/src/Huffman.cpp
+//   Huffman-or-Golomb choice, container layout  CompressionLib/src/CompressedImage.cpp:359-460, 635-707
+// Huffman ties are broken the way the reference's only toolchain (MSVC STL) breaks them; see
+// MsvcHashOrder in the .cpp.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+namespace mpc {
+
+class BitWriter {
+public:
+    void put(uint64_t value, int width);            // MSB first; width 0..64
+    void append(const BitWriter& other);
+    size_t bit_size() const { return nbits_; }
+    std::vector<uint8_t> bytes() const;             // zero-padded to a whole byte (BitBuffer::Save)
+private:
+    std::vector<uint64_t> words_;
+    size_t nbits_ = 0;
+};
+
+class BitReader {
+public:
+    BitReader(const uint8_t* data, size_t nbytes) : p_(data), nbits_(8 * nbytes) {}
+    // BitBuffer::ReadBits: the width is clipped to what remains; past the end it returns 0
+    uint64_t get(int width);
+    size_t remaining() const { return nbits_ - pos_; }
+private:
+    const uint8_t* p_;
+    size_t nbits_;
+    size_t pos_ = 0;
+};
+
+inline uint32_t zigzag_encode(int32_t x) { return (static_cast<uint32_t>(x) << 1) ^ static_cast<uint32_t>(x >> 31); }
+inline int32_t zigzag_decode(uint32_t x) { return static_cast<int32_t>((x >> 1) ^ static_cast<uint32_t>(-static_cast<int64_t>(x & 1))); }
+
+uint32_t golomb_length(uint32_t value, uint32_t m);
+void golomb_write(uint32_t value, uint32_t m, BitWriter& out);
+uint32_t golomb_read(uint32_t m, BitReader& in);
+
+void huffman_encode(const uint16_t* data, size_t n, BitWriter& out);
+bool huffman_decode(BitReader& in, std::vector<uint16_t>& out);          // false = "Invalid bitstream"
+
+std::vector<uint16_t> rle_encode(const uint16_t* data, size_t n);
+std::vector<uint16_t> rle_decode(const uint16_t* data, size_t n);
+
+void write_huffman_or_golomb(const uint16_t* data, size_t n, BitWriter& out);
+bool read_huffman_or_golomb(BitReader& in, size_t length, std::vector<uint16_t>& out);
+
+struct Streams {
+    int width = 0, height = 0, K = 0, block_size = 0;
+    uint16_t quant[3][32] = {};
+    std::vector<uint16_t> lengths;                  // 3 per tile, x-outer / y-inner tile order
+    std::vector<std::vector<uint16_t>> codes;       // [6K]: codes[2K*ch + 2i] deltaId, [+1] intCoeff of step i
+};
+
+// writeCompressed: codes are taken as the encoder holds them (DC coefficients not yet differenced)
+std::vector<uint8_t> write_compressed(const Streams& s);
+// readCompressed: codes come back with the DC differencing undone; false = invalid data
+bool read_compressed(const uint8_t* bytes, size_t nbytes, Streams& out);
+
+// Build the streams from per-tile records in the reference's visiting order (tile t = tx*tiles_y + ty):
+// counts[t*3+ch], choices[(t*3+ch)*K + i] = deltaId | intCoeff << 16.   (encodeImage, CompressedImage.cpp:555-572)
+Streams assemble_streams(int width, int height, int K, int block_size, const double* quant /*[3*K]*/,
+                         const uint16_t* counts, const uint32_t* choices);
+
+}  // namespace mpc

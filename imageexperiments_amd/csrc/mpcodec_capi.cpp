@@ -7,11 +7,14 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <stdexcept>
 #include <vector>
 
+#include "host_bitstream.h"
+#include "host_codec.h"
 #include "host_dictionary.h"
 #include "mp_device.h"
 
@@ -103,6 +106,12 @@ mpc_status ensure_workspace(mpc_context* c, long long tile_channels) {
 constexpr int kBaseParts = 8;
 constexpr int kRowParts = 4;
 
+// tuning overrides for experiments (results never depend on them)
+int env_int(const char* name, int fallback) {
+    const char* v = std::getenv(name);
+    return (v && *v) ? std::atoi(v) : fallback;
+}
+
 mpc_status run_pursuit(mpc_context* c, const mpc::FrameInput& in, const mpc::Outputs& out, const double* d_quant,
                        long long total_tc, void* stream) {
     mpc_status st = ensure_workspace(c, total_tc);
@@ -111,7 +120,8 @@ mpc_status run_pursuit(mpc_context* c, const mpc::FrameInput& in, const mpc::Out
     for (long long begin = 0; begin < total_tc; begin += c->ws_cap) {
         const long long n = (total_tc - begin < c->ws_cap) ? total_tc - begin : c->ws_cap;
         const int err = mpc::enqueue_pursuit(dict, c->ws, in, out, d_quant, c->K, begin, static_cast<int>(n),
-                                             kBaseParts, kRowParts, c->max_waves, stream);
+                                             env_int("MPC_BASE_PARTS", kBaseParts), env_int("MPC_ROW_PARTS", kRowParts),
+                                             env_int("MPC_SWEEP_WAVES", c->max_waves), stream);
         if (err != 0) return fail(MPC_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(err)));
     }
     return MPC_OK;
@@ -402,6 +412,172 @@ mpc_status mpc_calc_mp(mpc_context* c, int channel, const double* quant_k, const
     mpc_status st = mpc_calc_mp_batch(c, channel, quant_k, input64, 1, choices, &n, nullptr, nullptr);
     if (st == MPC_OK) *count = n;
     return st;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host entropy stage / container
+// ------------------------------------------------------------------------------------------------
+struct mpc_streams {
+    mpc::Streams s;
+};
+
+namespace {
+uint8_t* give_bytes(const std::vector<uint8_t>& v, size_t* n) {
+    uint8_t* p = static_cast<uint8_t*>(std::malloc(v.empty() ? 1 : v.size()));
+    if (p && !v.empty()) std::memcpy(p, v.data(), v.size());
+    *n = v.size();
+    return p;
+}
+uint16_t* give_u16(const std::vector<uint16_t>& v, size_t* n) {
+    uint16_t* p = static_cast<uint16_t*>(std::malloc(v.empty() ? 2 : v.size() * 2));
+    if (p && !v.empty()) std::memcpy(p, v.data(), v.size() * 2);
+    *n = v.size();
+    return p;
+}
+}  // namespace
+
+void mpc_free(void* p) { std::free(p); }
+
+mpc_status mpc_write_compressed(int width, int height, int K, int block_size, const double* quant,
+                                const uint16_t* lengths, size_t n_lengths, const uint16_t* const* codes,
+                                const size_t* code_lengths, uint8_t** bytes, size_t* nbytes) {
+    if (!quant || !bytes || !nbytes || (!lengths && n_lengths) || !codes || !code_lengths || K < 1 || K > MPC_MAX_K)
+        return fail(MPC_ERR_ARGUMENT, "bad argument");
+    mpc::Streams s;
+    s.width = width; s.height = height; s.K = K; s.block_size = block_size;
+    for (int ch = 0; ch < 3; ++ch)
+        for (int i = 0; i < K; ++i) s.quant[ch][i] = static_cast<uint16_t>(quant[ch * K + i]);
+    s.lengths.assign(lengths, lengths + n_lengths);
+    s.codes.resize(static_cast<size_t>(6 * K));
+    for (int i = 0; i < 6 * K; ++i) s.codes[i].assign(codes[i], codes[i] + code_lengths[i]);
+    *bytes = give_bytes(mpc::write_compressed(s), nbytes);
+    return *bytes ? MPC_OK : fail(MPC_ERR_ALLOC, "out of memory");
+}
+
+mpc_status mpc_assemble_streams(int width, int height, int K, int block_size, const double* quant,
+                                const uint16_t* counts, const mpc_basis_choice* choices, uint8_t** bytes, size_t* nbytes) {
+    if (!quant || !counts || !choices || !bytes || !nbytes || K < 1 || K > MPC_MAX_K || block_size < 1 || width < 1 || height < 1)
+        return fail(MPC_ERR_ARGUMENT, "bad argument");
+    const mpc::Streams s = mpc::assemble_streams(width, height, K, block_size, quant, counts,
+                                                 reinterpret_cast<const uint32_t*>(choices));
+    *bytes = give_bytes(mpc::write_compressed(s), nbytes);
+    return *bytes ? MPC_OK : fail(MPC_ERR_ALLOC, "out of memory");
+}
+
+mpc_status mpc_read_compressed(const uint8_t* bytes, size_t nbytes, mpc_streams** out) {
+    if (!bytes || !out) return fail(MPC_ERR_ARGUMENT, "null argument");
+    mpc_streams* h = new (std::nothrow) mpc_streams;
+    if (!h) return fail(MPC_ERR_ALLOC, "out of memory");
+    if (!mpc::read_compressed(bytes, nbytes, h->s)) {
+        delete h;
+        return fail(MPC_ERR_BITSTREAM, "Invalid input data");
+    }
+    *out = h;
+    return MPC_OK;
+}
+
+mpc_status mpc_streams_info(const mpc_streams* h, int* width, int* height, int* K, int* block_size) {
+    if (!h) return fail(MPC_ERR_ARGUMENT, "null streams");
+    if (width) *width = h->s.width;
+    if (height) *height = h->s.height;
+    if (K) *K = h->s.K;
+    if (block_size) *block_size = h->s.block_size;
+    return MPC_OK;
+}
+
+mpc_status mpc_streams_quant(const mpc_streams* h, uint16_t* quant) {
+    if (!h || !quant) return fail(MPC_ERR_ARGUMENT, "null argument");
+    for (int ch = 0; ch < 3; ++ch)
+        for (int i = 0; i < h->s.K; ++i) quant[ch * h->s.K + i] = h->s.quant[ch][i];
+    return MPC_OK;
+}
+
+size_t mpc_streams_length(const mpc_streams* h, int index) {
+    if (!h) return 0;
+    if (index < 0) return h->s.lengths.size();
+    return index < static_cast<int>(h->s.codes.size()) ? h->s.codes[index].size() : 0;
+}
+
+mpc_status mpc_streams_copy(const mpc_streams* h, int index, uint16_t* dst) {
+    if (!h || !dst) return fail(MPC_ERR_ARGUMENT, "null argument");
+    const std::vector<uint16_t>* v = nullptr;
+    if (index < 0) v = &h->s.lengths;
+    else if (index < static_cast<int>(h->s.codes.size())) v = &h->s.codes[index];
+    if (!v) return fail(MPC_ERR_ARGUMENT, "stream index %d out of range", index);
+    if (!v->empty()) std::memcpy(dst, v->data(), v->size() * 2);
+    return MPC_OK;
+}
+
+void mpc_streams_free(mpc_streams* h) { delete h; }
+
+mpc_status mpc_huffman_encode(const uint16_t* data, size_t n, uint8_t** bytes, size_t* nbytes) {
+    if ((!data && n) || !bytes || !nbytes) return fail(MPC_ERR_ARGUMENT, "null argument");
+    mpc::BitWriter w;
+    mpc::huffman_encode(data, n, w);
+    *bytes = give_bytes(w.bytes(), nbytes);
+    return *bytes ? MPC_OK : fail(MPC_ERR_ALLOC, "out of memory");
+}
+
+mpc_status mpc_huffman_decode(const uint8_t* bytes, size_t nbytes, uint16_t** data, size_t* n) {
+    if (!bytes || !data || !n) return fail(MPC_ERR_ARGUMENT, "null argument");
+    mpc::BitReader r(bytes, nbytes);
+    std::vector<uint16_t> out;
+    if (!mpc::huffman_decode(r, out)) return fail(MPC_ERR_BITSTREAM, "Invalid bitstream");
+    *data = give_u16(out, n);
+    return *data ? MPC_OK : fail(MPC_ERR_ALLOC, "out of memory");
+}
+
+mpc_status mpc_rle_encode(const uint16_t* data, size_t n, uint16_t** out, size_t* n_out) {
+    if ((!data && n) || !out || !n_out) return fail(MPC_ERR_ARGUMENT, "null argument");
+    *out = give_u16(mpc::rle_encode(data, n), n_out);
+    return *out ? MPC_OK : fail(MPC_ERR_ALLOC, "out of memory");
+}
+
+mpc_status mpc_rle_decode(const uint16_t* data, size_t n, uint16_t** out, size_t* n_out) {
+    if ((!data && n) || !out || !n_out) return fail(MPC_ERR_ARGUMENT, "null argument");
+    *out = give_u16(mpc::rle_decode(data, n), n_out);
+    return *out ? MPC_OK : fail(MPC_ERR_ALLOC, "out of memory");
+}
+
+// compressed::encodeImage: device tile encode + host entropy stage
+mpc_status mpc_encode_image(mpc_context* c, const uint8_t* rgb, int width, int height, const double* quant,
+                            uint8_t** bytes, size_t* nbytes) {
+    if (!c || !rgb || !bytes || !nbytes) return fail(MPC_ERR_ARGUMENT, "null argument");
+    if (c->device < 0) return fail(MPC_ERR_NO_DEVICE, "context was created without a device; there is no CPU fallback");
+    const int tiles_x = (width + 7) / 8, tiles_y = (height + 7) / 8;
+    const size_t tiles = static_cast<size_t>(tiles_x) * tiles_y;
+    std::vector<uint16_t> counts(tiles * 3);
+    std::vector<mpc_basis_choice> choices(tiles * 3 * c->K);
+    mpc_status st = mpc_encode_tiles(c, rgb, width, height, static_cast<size_t>(3) * width, 0, tiles_y, quant, counts.data(),
+                                     choices.data(), nullptr, nullptr);
+    if (st != MPC_OK) return st;
+    return mpc_assemble_streams(width, height, c->K, c->block_size, quant ? quant : c->quant.data(), counts.data(),
+                                choices.data(), bytes, nbytes);
+}
+
+// compressed::decodeImage (host in this round)
+mpc_status mpc_decode_image(const mpc_context* c, const uint8_t* bytes, size_t nbytes, uint8_t** rgb, int* width, int* height) {
+    if (!bytes || !rgb || !width || !height) return fail(MPC_ERR_ARGUMENT, "null argument");
+    mpc::Streams s;
+    if (!mpc::read_compressed(bytes, nbytes, s)) return fail(MPC_ERR_BITSTREAM, "Invalid input data");
+    mpc::Dictionary local;
+    const mpc::Dictionary* dict = nullptr;
+    if (c && c->block_size == s.block_size) dict = &c->dict;
+    else {
+        try { local = mpc::build_dictionary(s.block_size); } catch (const std::exception& e) { return fail(MPC_ERR_ARGUMENT, "%s", e.what()); }
+        dict = &local;
+    }
+    std::vector<uint8_t> out;
+    if (!mpc::decode_streams(*dict, s, out)) return fail(MPC_ERR_BITSTREAM, "Invalid bitstream");
+    size_t n = 0;
+    *rgb = give_bytes(out, &n);
+    *width = s.width;
+    *height = s.height;
+    return *rgb ? MPC_OK : fail(MPC_ERR_ALLOC, "out of memory");
+}
+
+double mpc_psnr(const uint8_t* original, const uint8_t* decoded, int width, int height) {
+    return mpc::psnr(original, decoded, width, height);
 }
 
 }  // extern "C"

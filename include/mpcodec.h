@@ -137,6 +137,53 @@ mpc_status mpc_calc_mp_batch(mpc_context* ctx, int channel, const double* quant_
  * (stream capture) reserve first.  Larger inputs are processed in batches of 262144 tiles. */
 mpc_status mpc_reserve(mpc_context* ctx, long long max_tiles);
 
+/* ---- host entropy stage and container (stays on the host; bytes identical to the reference) ----------
+ * Buffers returned through `uint8_t**` / `uint16_t**` are malloc'ed by the library: release with mpc_free. */
+typedef struct mpc_streams mpc_streams;
+
+void mpc_free(void* p);
+
+/* writeCompressed (CompressedImage.cpp:403): header, DC differencing of codes[1], [2K+1], [4K+1], optional RLE,
+ * Huffman-or-Golomb per stream.  quant[3*K]; lengths = 3 per tile in x-outer / y-inner tile order;
+ * codes[6K] / code_lengths[6K] = the streams codes[2K*ch + 2i] (deltaId) and [+1] (intCoeff) as the encoder
+ * holds them (DC coefficients NOT yet differenced). */
+mpc_status mpc_write_compressed(int width, int height, int K, int block_size, const double* quant,
+                                const uint16_t* lengths, size_t n_lengths, const uint16_t* const* codes,
+                                const size_t* code_lengths, uint8_t** bytes, size_t* nbytes);
+
+/* The host half of encodeImage (CompressedImage.cpp:555-575): per-tile records of a WHOLE frame, tile
+ * t = tx*tiles_y + ty (what mpc_encode_tiles returns for rows [0, tiles_y)), -> container bytes. */
+mpc_status mpc_assemble_streams(int width, int height, int K, int block_size, const double* quant,
+                                const uint16_t* counts, const mpc_basis_choice* choices, uint8_t** bytes, size_t* nbytes);
+
+/* readCompressed (CompressedImage.cpp:635): parse a container; streams come back with the DC differencing
+ * undone.  index -1 = lengths, 0..6K-1 = codes[index]. */
+mpc_status mpc_read_compressed(const uint8_t* bytes, size_t nbytes, mpc_streams** out);
+mpc_status mpc_streams_info(const mpc_streams* s, int* width, int* height, int* K, int* block_size);
+mpc_status mpc_streams_quant(const mpc_streams* s, uint16_t* quant /* [3*K] */);
+size_t mpc_streams_length(const mpc_streams* s, int index);
+mpc_status mpc_streams_copy(const mpc_streams* s, int index, uint16_t* dst);
+void mpc_streams_free(mpc_streams* s);
+
+/* huffman::huffmanEncode / huffmanDecode (Huffman.h:15-19), runLengthEncode / runLengthDecode (:12-13) */
+mpc_status mpc_huffman_encode(const uint16_t* data, size_t n, uint8_t** bytes, size_t* nbytes);
+mpc_status mpc_huffman_decode(const uint8_t* bytes, size_t nbytes, uint16_t** data, size_t* n);
+mpc_status mpc_rle_encode(const uint16_t* data, size_t n, uint16_t** out, size_t* n_out);
+mpc_status mpc_rle_decode(const uint16_t* data, size_t n, uint16_t** out, size_t* n_out);
+
+/* compressed::encodeImage (CompressedImage.h:59): rgb host buffer, 3*width bytes per row; quant NULL = context
+ * tables.  Tile encode on the device, entropy stage on the host. */
+mpc_status mpc_encode_image(mpc_context* ctx, const uint8_t* rgb, int width, int height, const double* quant,
+                            uint8_t** bytes, size_t* nbytes);
+
+/* compressed::decodeImage (CompressedImage.h:75); ctx may be NULL (the dictionary is then rebuilt, ~1 s).
+ * Host implementation in this round. */
+mpc_status mpc_decode_image(const mpc_context* ctx, const uint8_t* bytes, size_t nbytes, uint8_t** rgb, int* width,
+                            int* height);
+
+/* compressed::calculatePSNR (CompressedImage.h:57) */
+double mpc_psnr(const uint8_t* original, const uint8_t* decoded, int width, int height);
+
 #ifdef __cplusplus
 }
 #endif
