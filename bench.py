@@ -147,6 +147,7 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    ctx.kernel_timing(True)                                  # HIP events around every base-sweep launch, on this stream
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
@@ -157,12 +158,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))      # HIP events on the launch stream
+    base_ms_total, base_launches = ctx.read_kernel_timing()             # dominant kernel, HIP events on the launch stream
+    ctx.kernel_timing(False)
+    pursuit_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))     # all kernels of one step's K-step pursuit
     swept_total = int(d_swept.to(torch.int64).sum().item())             # S summed over this rank's tile-channels
-    sweep_bytes = 64 * 8 * swept_total                                   # 64 * sizeof(double) * S
-    achieved_gbs = sweep_bytes / (kernel_ms * 1e-3) / 1e9
-    mac_lanes = 64 * swept_total                                         # f64 mul+add pairs executed per launch
-    valu_gops = 2 * mac_lanes / (kernel_ms * 1e-3) / 1e9                # separate v_mul_f64 + v_add_f64
+    sweeps = int(torch.clamp(d_counts.to(torch.int64) + 1, max=K).sum().item())   # min(count+1, K) per tile-channel
+    # algorithmic bytes = 64 * sizeof(double) * rows correlated.  The base sweep correlates 510 rows
+    # per executed sweep; the remaining S - 510*sweeps rows belong to the detail kernels.
+    base_bytes_per_step = 64 * 8 * 510 * sweeps
+    base_ms = base_ms_total / max(base_launches, 1)                     # average duration of ONE base-sweep launch
+    base_bytes_per_launch = base_bytes_per_step * args.steps / max(base_launches, 1)
+    achieved_gbs = base_bytes_per_launch / (base_ms * 1e-3) / 1e9
+    sweep_bytes = 64 * 8 * swept_total
+    valu_gops = 2 * 64 * 510 * sweeps * args.steps / (base_ms_total * 1e-3) / 1e9   # v_mul_f64 + v_add_f64 lanes/s in the base sweep
 
     if rank == 0:
         pixels_per_step = frames * W * H
@@ -195,10 +203,14 @@ def main():
                        "tiles_per_rank": tiles},
             "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "mp_base_kernel (dominant of the per-step sequence; kernel_ms = whole K-step pursuit)", "kernel_ms": round(kernel_ms, 4),
-                         "algorithmic_bytes_per_launch": sweep_bytes, "swept_rows_per_tile": round(swept_total / tiles, 1),
-                         "note": "algorithmic sweep bytes = 64*8*S (SURVEY 8d); the dictionary is served by the scalar "
-                                 "cache/L2, so this exceeds real HBM traffic by design; the binding unit is f64 VALU issue",
+                         "kernel": "mp_base_kernel", "kernel_avg_ms": round(base_ms, 5), "kernel_launches_per_step": base_launches // args.steps,
+                         "algorithmic_bytes_per_launch": int(base_bytes_per_launch),
+                         "whole_pursuit": {"ms_per_step": round(pursuit_ms, 4), "algorithmic_bytes_per_step": sweep_bytes,
+                                           "GB_per_s": round(sweep_bytes / (pursuit_ms * 1e-3) / 1e9, 1),
+                                           "swept_rows_per_tile": round(swept_total / tiles, 1)},
+                         "note": "algorithmic bytes = 64*8*rows correlated (SURVEY 8d); dictionary rows are served by the scalar "
+                                 "cache/L2, so this exceeds real memory traffic by design (traffic = PMC FETCH/WRITE of the whole "
+                                 "step, profiles/r01_pmc_*.json); the unit that binds is f64 VALU issue (f64_valu)",
                          "f64_valu": {"achieved_Ginstr_lanes": round(valu_gops, 1), "peak": F64_VALU_PEAK_GOPS,
                                       "frac": round(valu_gops / F64_VALU_PEAK_GOPS, 4)}},
         }

@@ -723,7 +723,7 @@ Workspace carve_workspace(void* device_mem, int cap, int K) { return carve(stati
 
 int enqueue_pursuit(const DictDevice& dict, const Workspace& ws, const FrameInput& in, const Outputs& out,
                     const double* quant_dev, int K, long long tc_begin, int n, int parts, int row_parts, int sweep_waves,
-                    void* stream_)
+                    void* stream_, void** base_events)
 {
     hipStream_t s = static_cast<hipStream_t>(stream_);
     if (n < 1 || n > ws.cap) return (int)hipErrorInvalidValue;
@@ -747,8 +747,10 @@ int enqueue_pursuit(const DictDevice& dict, const Workspace& ws, const FrameInpu
             hipLaunchKernelGGL(mp_bucket_kernel, dim3(1), dim3(1024), 0, s, ws, step & 1);
             hipLaunchKernelGGL(mp_fill_kernel, dim3(clampu(max_slabs, 2048u)), dim3(256), 0, s, ws, cur);
         }
+        if (base_events) (void)hipEventRecord(static_cast<hipEvent_t>(base_events[2 * step]), s);
         hipLaunchKernelGGL(mp_base_kernel, dim3(clampu(max_groups * (unsigned)parts, slots)), dim3(64), 0, s, ws, dict, cur,
                            parts);
+        if (base_events) (void)hipEventRecord(static_cast<hipEvent_t>(base_events[2 * step + 1]), s);
         if (step > 0) {
             hipLaunchKernelGGL(mp_detail0_kernel, dim3(clampu(max_groups * (unsigned)row_parts, slots)), dim3(64), 0, s, ws,
                                dict, cur, row_parts);

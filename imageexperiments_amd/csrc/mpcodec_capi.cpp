@@ -63,6 +63,10 @@ struct mpc_context {
     int base_rows_padded = 0;
     int max_waves = 0;
     int num_cus = 0;
+    // optional live timing of the base-sweep launches (mpc_kernel_timing_*)
+    bool timing = false;
+    std::vector<hipEvent_t> timing_events;      // 2 per launch, grown on demand
+    size_t timing_used = 0;
 };
 
 namespace {
@@ -119,9 +123,20 @@ mpc_status run_pursuit(mpc_context* c, const mpc::FrameInput& in, const mpc::Out
     const mpc::DictDevice dict = dict_device(c);
     for (long long begin = 0; begin < total_tc; begin += c->ws_cap) {
         const long long n = (total_tc - begin < c->ws_cap) ? total_tc - begin : c->ws_cap;
+        void** events = nullptr;
+        if (c->timing) {
+            const size_t need = c->timing_used + 2 * static_cast<size_t>(c->K);
+            while (c->timing_events.size() < need) {
+                hipEvent_t e;
+                if (hipEventCreate(&e) != hipSuccess) return fail(MPC_ERR_HIP, "hipEventCreate failed");
+                c->timing_events.push_back(e);
+            }
+            events = reinterpret_cast<void**>(c->timing_events.data() + c->timing_used);
+            c->timing_used = need;
+        }
         const int err = mpc::enqueue_pursuit(dict, c->ws, in, out, d_quant, c->K, begin, static_cast<int>(n),
                                              env_int("MPC_BASE_PARTS", kBaseParts), env_int("MPC_ROW_PARTS", kRowParts),
-                                             env_int("MPC_SWEEP_WAVES", c->max_waves), stream);
+                                             env_int("MPC_SWEEP_WAVES", c->max_waves), stream, events);
         if (err != 0) return fail(MPC_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(err)));
     }
     return MPC_OK;
@@ -195,6 +210,7 @@ void mpc_context_destroy(mpc_context* c) {
         (void)hipFree(c->d_rows);
         (void)hipFree(c->d_rowoff);
         (void)hipFree(c->d_workspace);
+        for (hipEvent_t e : c->timing_events) (void)hipEventDestroy(e);
     }
     delete c;
 }
@@ -395,6 +411,30 @@ mpc_status mpc_calc_mp_batch(mpc_context* c, int channel, const double* quant_k,
     (void)hipFree(d_q);
     if (st != MPC_OK) return st;
     if (e != hipSuccess) return fail(MPC_ERR_HIP, "HIP failure: %s", hipGetErrorString(e));
+    return MPC_OK;
+}
+
+// live timing of the dominant kernel (mp_base_kernel) with HIP events on the launch stream
+void mpc_kernel_timing_enable(mpc_context* c, int on) {
+    if (!c) return;
+    c->timing = on != 0;
+    c->timing_used = 0;
+}
+
+mpc_status mpc_kernel_timing_read(mpc_context* c, double* total_ms, long long* launches) {
+    if (!c || !total_ms || !launches) return fail(MPC_ERR_ARGUMENT, "null argument");
+    if (c->device < 0) return fail(MPC_ERR_NO_DEVICE, "context was created without a device");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipDeviceSynchronize());
+    double sum = 0.0;
+    for (size_t i = 0; i + 1 < c->timing_used; i += 2) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->timing_events[i], c->timing_events[i + 1]));
+        sum += ms;
+    }
+    *total_ms = sum;
+    *launches = static_cast<long long>(c->timing_used / 2);
+    c->timing_used = 0;
     return MPC_OK;
 }
 

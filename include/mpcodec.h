@@ -137,6 +137,12 @@ mpc_status mpc_calc_mp_batch(mpc_context* ctx, int channel, const double* quant_
  * (stream capture) reserve first.  Larger inputs are processed in batches of 262144 tiles. */
 mpc_status mpc_reserve(mpc_context* ctx, long long max_tiles);
 
+/* Live timing of the dominant kernel (the base sweep, mp_base_kernel): while enabled every launch of it is
+ * bracketed by HIP events on the launch stream.  mpc_kernel_timing_read synchronises, returns the summed
+ * duration and the number of launches since the last read/enable, and resets.  Measurement only. */
+void mpc_kernel_timing_enable(mpc_context* ctx, int on);
+mpc_status mpc_kernel_timing_read(mpc_context* ctx, double* total_ms, long long* launches);
+
 /* ---- host entropy stage and container (stays on the host; bytes identical to the reference) ----------
  * Buffers returned through `uint8_t**` / `uint16_t**` are malloc'ed by the library: release with mpc_free. */
 typedef struct mpc_streams mpc_streams;
