@@ -9,7 +9,7 @@
 //     bucket   (s>0) prefix-sum the per-block item counts, emit chunk descriptors
 //     fill     (s>0) scatter (tile-channel, block) items into their block's bucket
 //     base     correlate r with the 510 shared base atoms                          (Select, MatchingPursuit.cpp:7-25)
-//     detail0  (s>0) correlate r with DetailBasis[0] (the DC block nearly every tile unlocks first; no bucketing)
+//              and (s>0) with DetailBasis[0], the block the DC atom unlocks for nearly every tile (no bucketing)
 //     detail   (s>0) correlate r with every other unlocked detail block, bucketed by (channel, block)
 //     finish   argmax in dictionary order, quantise, record, residual update, unlock block, compact
 //                                                                                   (MatchingPursuit.cpp:55-71)
@@ -49,8 +49,8 @@ struct Workspace {
     double* r;                       // [cap][64] residuals
     double* part_val;                // [cap][kMaxParts] best projection of each base atom range
     int* part_idx;                   // [cap][kMaxParts]
-    double* cand0_val;               // [cap][kMaxRowParts] best projection on DetailBasis[0] (if unlocked), per row range
-    int* cand0_row;                  // [cap][kMaxRowParts]
+    double* cand0_val;               // [cap] best projection on DetailBasis[0] (if unlocked)
+    int* cand0_row;                  // [cap]
     int* prev_id;                    // [cap]
     int* nblk;                       // [cap] entries in blk_list
     int* extra_rows;                 // [cap] rows appended after the base part (duplicates included)

@@ -184,15 +184,19 @@ __device__ __forceinline__ void decode_group(const UnitMap& m, int gi, int& ch, 
 }
 
 // base sweep: unit = 64 entries of one channel's active list x one of `parts` ranges of the 510 base atoms;
-// the ranges are combined in index order by the finish kernel.
-__global__ __launch_bounds__(64, 3) void mp_base_kernel(const Workspace ws, const DictDevice dict, int cur, int parts)
+// the ranges are combined in index order by the finish kernel.  With `with_detail0` one more range per group
+// sweeps DetailBasis[0] of the group's channel (63 rows, unlocked by the DC atom, i.e. held by nearly every
+// tile-channel after step 0 -- no bucketing needed; lanes that have not unlocked it idle).
+__global__ __launch_bounds__(64, 3) void mp_base_kernel(const Workspace ws, const DictDevice dict, int cur, int parts,
+                                                        int with_detail0)
 {
     const int lane = threadIdx.x;
     if (blockIdx.x == 0 && lane < 3) ws.counters[(cur ^ 1) * 3 + lane] = 0;      // next step's active counts
     const UnitMap m = unit_map(ws.counters, cur);
     const int total_groups = m.groups();
-    const int n_units = total_groups * parts;
+    const int n_units = total_groups * (parts + with_detail0);
     const int per = (dict.base_rows_padded + parts - 1) / parts;
+    const int rows0 = __builtin_amdgcn_readfirstlane(dict.block_rows[0]);
     for (int u = blockIdx.x; u < n_units; u += gridDim.x) {
         const int part = __builtin_amdgcn_readfirstlane(u / total_groups);
         int ch, group;
@@ -201,16 +205,35 @@ __global__ __launch_bounds__(64, 3) void mp_base_kernel(const Workspace ws, cons
         const int pos = group * 64 + lane;
         const bool valid = pos < n_act;
         const int tc = ws.act[cur][ch][valid ? pos : group * 64];
-        double r[N];
-        load_residual(r, ws.r + (long long)tc * N);
-        const int a0 = part * per;
-        const int a1 = (a0 + per < dict.base_rows_padded) ? a0 + per : dict.base_rows_padded;
-        double best_val;
-        int best_row;
-        sweep_rows(r, as_scalar(dict.base) + (long long)a0 * N, a1 - a0, best_val, best_row);
-        if (valid) {
-            ws.part_val[(long long)tc * kMaxParts + part] = best_val;
-            ws.part_idx[(long long)tc * kMaxParts + part] = (best_row < 0) ? -1 : a0 + best_row;
+        if (part < parts) {
+            double r[N];
+            load_residual(r, ws.r + (long long)tc * N);
+            const int a0 = part * per;
+            const int a1 = (a0 + per < dict.base_rows_padded) ? a0 + per : dict.base_rows_padded;
+            double best_val;
+            int best_row;
+            sweep_rows(r, as_scalar(dict.base) + (long long)a0 * N, a1 - a0, best_val, best_row);
+            if (valid) {
+                ws.part_val[(long long)tc * kMaxParts + part] = best_val;
+                ws.part_idx[(long long)tc * kMaxParts + part] = (best_row < 0) ? -1 : a0 + best_row;
+            }
+        } else {
+            bool has0 = false;
+            if (valid) {
+                const int nb = ws.nblk[tc];
+                for (int i = 0; i < nb; ++i)
+                    if (ws.blk_list[(long long)tc * kMaxDeviceK + i] == 0) has0 = true;     // first occurrence of block 0
+            }
+            if (!__ballot(has0)) continue;
+            double r[N];
+            load_residual(r, ws.r + (long long)tc * N);
+            double best_val;
+            int best_row;
+            sweep_rows(r, as_scalar(dict.detail) + (long long)ch * dict.detail_rows * N, rows0, best_val, best_row);
+            if (has0) {
+                ws.cand0_val[tc] = best_val;
+                ws.cand0_row[tc] = best_row;
+            }
         }
     }
 }
@@ -237,45 +260,6 @@ __device__ __forceinline__ double touch_rows(const double* first_row, int nrows,
         if (line < lines) acc += first_row[line * 16];
     }
     return acc;
-}
-
-// DetailBasis[0] (unlocked by the DC atom, i.e. by nearly every tile-channel at step 0): no bucketing -- a unit
-// is 64 consecutive entries of a channel's active list (lanes that have not unlocked block 0 idle) x one of
-// `row_parts` ranges of the block's 63 rows.
-__global__ __launch_bounds__(64, 3) void mp_detail0_kernel(const Workspace ws, const DictDevice dict, int cur, int row_parts)
-{
-    const int lane = threadIdx.x;
-    const UnitMap m = unit_map(ws.counters, cur);
-    const int total_groups = m.groups();
-    const int n_units = total_groups * row_parts;
-    const int rows0 = dict.block_rows[0];
-    for (int u = blockIdx.x; u < n_units; u += gridDim.x) {
-        const int part = __builtin_amdgcn_readfirstlane(u / total_groups);
-        int ch, group;
-        decode_group(m, u - part * total_groups, ch, group);
-        const int n_act = (int)scalar_counter(ws.counters, cur * 3 + ch);
-        const int pos = group * 64 + lane;
-        const bool valid = pos < n_act;
-        const int tc = ws.act[cur][ch][valid ? pos : group * 64];
-        bool has0 = false;
-        if (valid) {
-            const int nb = ws.nblk[tc];
-            for (int i = 0; i < nb; ++i)
-                if (ws.blk_list[(long long)tc * kMaxDeviceK + i] == 0) has0 = true;     // first occurrence of block 0
-        }
-        if (!__ballot(has0)) continue;
-        double r[N];
-        load_residual(r, ws.r + (long long)tc * N);
-        int lo, hi;
-        row_range(rows0, row_parts, part, lo, hi);
-        double best_val;
-        int best_row;
-        sweep_rows(r, as_scalar(dict.detail) + ((long long)ch * dict.detail_rows + lo) * N, hi - lo, best_val, best_row);
-        if (has0) {
-            ws.cand0_val[(long long)tc * kMaxRowParts + part] = best_val;
-            ws.cand0_row[(long long)tc * kMaxRowParts + part] = (best_row < 0) ? -1 : lo + best_row;
-        }
-    }
 }
 
 // every other block: work unit = (chunk of <= 64 items of one (channel, block) bucket) x (row range);
@@ -459,13 +443,14 @@ __global__ __launch_bounds__(256) void mp_finish_kernel(const Workspace ws, cons
         if (!(e & 0x8000u)) {               // a repeated block can never win: identical projections at a higher index
             const double* cv;
             const int* cr;
-            if (blk == 0) { cv = ws.cand0_val + (long long)tc * kMaxRowParts; cr = ws.cand0_row + (long long)tc * kMaxRowParts; }
+            int nparts = row_parts;
+            if (blk == 0) { cv = ws.cand0_val + tc; cr = ws.cand0_row + tc; nparts = 1; }
             else {
                 const long long slot = ws.item_slot[(long long)tc * kMaxDeviceK + i];
                 cv = ws.cand_val + slot * kMaxRowParts;
                 cr = ws.cand_row + slot * kMaxRowParts;
             }
-            for (int p = 0; p < row_parts; ++p) {       // row ranges in ascending order
+            for (int p = 0; p < nparts; ++p) {          // row ranges in ascending order
                 const double v = cv[p];
                 const int row = cr[p];
                 if (row >= 0 && __builtin_fabs(v) > __builtin_fabs(best_val)) {
@@ -694,8 +679,8 @@ Workspace carve(char* mem, int cap, int K, size_t* total)
     w.out_index = c.take<int>(n);
     for (int a = 0; a < 2; ++a)
         for (int ch = 0; ch < 3; ++ch) w.act[a][ch] = c.take<int>(n);
-    w.cand0_val = c.take<double>(n * kMaxRowParts);
-    w.cand0_row = c.take<int>(n * kMaxRowParts);
+    w.cand0_val = c.take<double>(n);
+    w.cand0_row = c.take<int>(n);
     w.upd_coeff = c.take<double>(n);
     w.upd_sel = c.take<int>(n);
     w.counters = c.take<unsigned>(16);
@@ -748,12 +733,10 @@ int enqueue_pursuit(const DictDevice& dict, const Workspace& ws, const FrameInpu
             hipLaunchKernelGGL(mp_fill_kernel, dim3(clampu(max_slabs, 2048u)), dim3(256), 0, s, ws, cur);
         }
         if (base_events) (void)hipEventRecord(static_cast<hipEvent_t>(base_events[2 * step]), s);
-        hipLaunchKernelGGL(mp_base_kernel, dim3(clampu(max_groups * (unsigned)parts, slots)), dim3(64), 0, s, ws, dict, cur,
-                           parts);
+        hipLaunchKernelGGL(mp_base_kernel, dim3(clampu(max_groups * (unsigned)(parts + 1), slots)), dim3(64), 0, s, ws, dict,
+                           cur, parts, step > 0 ? 1 : 0);
         if (base_events) (void)hipEventRecord(static_cast<hipEvent_t>(base_events[2 * step + 1]), s);
         if (step > 0) {
-            hipLaunchKernelGGL(mp_detail0_kernel, dim3(clampu(max_groups * (unsigned)row_parts, slots)), dim3(64), 0, s, ws,
-                               dict, cur, row_parts);
             hipLaunchKernelGGL(mp_detail_kernel, dim3(clampu(max_groups * (unsigned)row_parts, slots)), dim3(64), 0, s, ws,
                                dict, row_parts, ws.cand_val);
         }

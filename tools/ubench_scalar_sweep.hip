@@ -64,6 +64,8 @@ __global__ __launch_bounds__(64) void sweep_pipe(const double* __restrict__ base
     cptr_t base = (cptr_t)(uintptr_t)base_g;
     double best = 0.0;
     unsigned long long t0 = __builtin_readcyclecounter();
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long st0 = __builtin_amdgcn_s_memtime();
     double ga[16], gb[16];
     load16(ga, base);
     for (int a = 0; a < natoms; a++) {
@@ -77,8 +79,11 @@ __global__ __launch_bounds__(64) void sweep_pipe(const double* __restrict__ base
         if (__builtin_fabs(tot) > __builtin_fabs(best)) best = tot;
     }
     unsigned long long t1 = __builtin_readcyclecounter();
+    const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long st1 = __builtin_amdgcn_s_memtime();
     outv[blockIdx.x * 64 + threadIdx.x] = best;
     if (threadIdx.x == 0) atomicAdd(cycles, t1 - t0);
+    if (threadIdx.x == 0 && blockIdx.x == 7) { cycles[1] = st1 - st0; cycles[2] = rt1 - rt0; }   // shader clocks vs 100 MHz ticks
 }
 
 void run_pipe(const double* d_base, int natoms, int wrap, int waves, double* d_out, unsigned long long* d_cyc)
@@ -92,9 +97,10 @@ void run_pipe(const double* d_base, int natoms, int wrap, int waves, double* d_o
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    unsigned long long cyc; hipMemcpy(&cyc, d_cyc, 8, hipMemcpyDeviceToHost);
-    printf("PIPE    waves=%5d wrap=%4d atoms=%d : %.3f ms, %.0f clk/atom/wave (ideal 512), MAC-lanes/s = %.2f T\n", waves, wrap,
-           natoms, ms, (double)cyc / waves / natoms, (double)waves * 64 * 64.0 * natoms / (ms * 1e-3) / 1e12);
+    unsigned long long cyc[3]; hipMemcpy(cyc, d_cyc, 24, hipMemcpyDeviceToHost);
+    printf("PIPE    waves=%5d wrap=%4d atoms=%d : %.3f ms, %.0f clk/atom/wave (ideal 512), MAC-lanes/s = %.2f T, shader clock %.0f MHz\n", waves, wrap,
+           natoms, ms, (double)cyc[0] / waves / natoms, (double)waves * 64 * 64.0 * natoms / (ms * 1e-3) / 1e12,
+           cyc[2] ? 100.0 * (double)cyc[1] / (double)cyc[2] : 0.0);
 }
 
 template <int SLOTS>
@@ -123,10 +129,9 @@ int main()
     for (size_t i = 0; i < h.size(); i++) h[i] = ((i * 2654435761u) % 1000) / 1000.0 - 0.5;
     double* d_base; double* d_out; unsigned long long* d_cyc;
     hipMalloc(&d_base, h.size() * 8); hipMemcpy(d_base, h.data(), h.size() * 8, hipMemcpyHostToDevice);
-    hipMalloc(&d_out, 8192 * 64 * 8); hipMalloc(&d_cyc, 8);
-    const int natoms = 2040;
+    hipMalloc(&d_out, 8192 * 64 * 8); hipMalloc(&d_cyc, 64);
+    const int natoms = 20400;
     for (int wrap : {510, 16}) {
-        for (int waves : {256, 1024, 2048, 3072}) run<1>(d_base, natoms, wrap, waves, d_out, d_cyc);
         for (int waves : {256, 1024, 2048, 3072}) run_pipe(d_base, natoms, wrap, waves, d_out, d_cyc);
 
     }
