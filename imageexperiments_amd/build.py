@@ -42,7 +42,38 @@ def build_library(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
+    verify_scalar_sweeps(LIB)
     return LIB
+
+
+def verify_scalar_sweeps(lib=LIB):
+    """Disassemble the gfx950 code object inside the library and check that every multiply of the sweep kernels
+    takes its dictionary operand from an SGPR (s_load-fed).  If the compiler ever decides the row pointer is
+    divergent it silently emits vector loads instead -- same results, ~6x slower -- so the build refuses that."""
+    import re
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        return None
+    data = open(lib, "rb").read()
+    starts = [m.start() for m in re.finditer(b"\x7fELF", data)]
+    report = {}
+    for k, st in enumerate(starts[1:]):
+        tmp = os.path.join(os.path.dirname(lib), f".co{k}.elf")
+        with open(tmp, "wb") as f:
+            f.write(data[st:])
+        out = subprocess.run([objdump, "-d", tmp], capture_output=True, text=True).stdout
+        os.remove(tmp)
+        for name in ("mp_base_kernel", "mp_detail_kernel"):
+            m = re.search(name + r"[^\n]*>:(.*?)s_endpgm", out, re.S)
+            if not m:
+                continue
+            muls = re.findall(r"v_mul_f64[^\n]*", m.group(1))
+            scalar = [x for x in muls if re.search(r", s\[\d+:\d+\]", x)]
+            report[name] = (len(scalar), len(muls))
+    bad = {k: v for k, v in report.items() if v[0] != v[1] or v[1] == 0}
+    if bad or not report:
+        raise RuntimeError(f"sweep kernels lost their scalar dictionary operands: {report}")
+    return report
 
 
 if __name__ == "__main__":

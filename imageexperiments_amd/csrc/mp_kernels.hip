@@ -44,7 +44,16 @@ __device__ __forceinline__ void load_group(double (&g)[16], scalar_f64_ptr src) 
     _Pragma("unroll") for (int i = 1; i < 16; ++i) tot += cur[i] * vec[(jbase) + i];     \
     __builtin_amdgcn_sched_barrier(0);
 
-__device__ __forceinline__ scalar_f64_ptr as_scalar(const double* p) { return (scalar_f64_ptr)(uintptr_t)p; }
+// A dictionary-row pointer for the scalar unit.  Both halves go through readfirstlane: the intrinsic's result is
+// uniform by definition, so the loads below stay s_load whatever the compiler's divergence analysis concluded
+// about the index arithmetic that produced `p` (it has flipped between builds; a vector-load sweep is 6x slower).
+__device__ __forceinline__ scalar_f64_ptr as_scalar(const double* p)
+{
+    const unsigned long long v = (unsigned long long)(uintptr_t)p;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return (scalar_f64_ptr)(uintptr_t)(((unsigned long long)hi << 32) | lo);
+}
 
 }  // namespace
 
@@ -65,6 +74,7 @@ __global__ __launch_bounds__(256) void mp_init_kernel(const Workspace ws, const 
             for (int c = 0; c < 3; ++c) {
                 ws.counters[c] = vec ? (c == in.vec_channel ? (unsigned)n : 0u) : (unsigned)(n / 3);
                 ws.counters[3 + c] = 0;
+                ws.counters[6 + c] = 0;                      // chunk cursor, chunk count, item count
             }
         }
     }
@@ -183,19 +193,34 @@ __device__ __forceinline__ void decode_group(const UnitMap& m, int gi, int& ch, 
     group = __builtin_amdgcn_readfirstlane(g);
 }
 
+// How finely a step's sweeps are cut is decided on the device from the active counts, identically by the
+// producer (sweep kernel) and the consumer (finish kernel): enough units for ~4 per wave of the persistent
+// grid (tail quantisation <= ~12 %), but no finer -- every extra range re-gathers the residuals and adds a
+// candidate for the finish kernel to read.
+__device__ __forceinline__ int effective_parts(int work_groups, int grid_waves, int max_parts)
+{
+    if (work_groups < 1) return 1;
+    int p = (4 * grid_waves + work_groups - 1) / work_groups;
+    if (p < 1) p = 1;
+    // wave-uniform by construction; tell the compiler, or everything derived from it (row pointers!) is
+    // treated as divergent and the dictionary loads stop being scalar
+    return __builtin_amdgcn_readfirstlane(p > max_parts ? max_parts : p);
+}
+
 // base sweep: unit = 64 entries of one channel's active list x one of `parts` ranges of the 510 base atoms;
 // the ranges are combined in index order by the finish kernel.  With `with_detail0` one more range per group
 // sweeps DetailBasis[0] of the group's channel (63 rows, unlocked by the DC atom, i.e. held by nearly every
 // tile-channel after step 0 -- no bucketing needed; lanes that have not unlocked it idle).
-__global__ __launch_bounds__(64, 3) void mp_base_kernel(const Workspace ws, const DictDevice dict, int cur, int parts,
-                                                        int with_detail0)
+__global__ __launch_bounds__(64, 3) void mp_base_kernel(const Workspace ws, const DictDevice dict, int cur, int max_parts,
+                                                        int with_detail0, int grid_hint)
 {
     const int lane = threadIdx.x;
     if (blockIdx.x == 0 && lane < 3) ws.counters[(cur ^ 1) * 3 + lane] = 0;      // next step's active counts
     const UnitMap m = unit_map(ws.counters, cur);
     const int total_groups = m.groups();
+    const int parts = effective_parts(total_groups, grid_hint, max_parts);
     const int n_units = total_groups * (parts + with_detail0);
-    const int per = (dict.base_rows_padded + parts - 1) / parts;
+    const int per = __builtin_amdgcn_readfirstlane((dict.base_rows_padded + parts - 1) / parts);
     const int rows0 = __builtin_amdgcn_readfirstlane(dict.block_rows[0]);
     for (int u = blockIdx.x; u < n_units; u += gridDim.x) {
         const int part = __builtin_amdgcn_readfirstlane(u / total_groups);
@@ -212,7 +237,7 @@ __global__ __launch_bounds__(64, 3) void mp_base_kernel(const Workspace ws, cons
             const int a1 = (a0 + per < dict.base_rows_padded) ? a0 + per : dict.base_rows_padded;
             double best_val;
             int best_row;
-            sweep_rows(r, as_scalar(dict.base) + (long long)a0 * N, a1 - a0, best_val, best_row);
+            sweep_rows(r, as_scalar(dict.base + (long long)a0 * N), __builtin_amdgcn_readfirstlane(a1 - a0), best_val, best_row);
             if (valid) {
                 ws.part_val[(long long)tc * kMaxParts + part] = best_val;
                 ws.part_idx[(long long)tc * kMaxParts + part] = (best_row < 0) ? -1 : a0 + best_row;
@@ -229,7 +254,7 @@ __global__ __launch_bounds__(64, 3) void mp_base_kernel(const Workspace ws, cons
             load_residual(r, ws.r + (long long)tc * N);
             double best_val;
             int best_row;
-            sweep_rows(r, as_scalar(dict.detail) + (long long)ch * dict.detail_rows * N, rows0, best_val, best_row);
+            sweep_rows(r, as_scalar(dict.detail + (long long)ch * dict.detail_rows * N), rows0, best_val, best_row);
             if (has0) {
                 ws.cand0_val[tc] = best_val;
                 ws.cand0_row[tc] = best_row;
@@ -241,7 +266,7 @@ __global__ __launch_bounds__(64, 3) void mp_base_kernel(const Workspace ws, cons
 // Row range `part` of `row_parts` of a block with `rows` rows: [lo, hi)
 __device__ __forceinline__ void row_range(int rows, int row_parts, int part, int& lo, int& hi)
 {
-    const int per = (rows + row_parts - 1) / row_parts;
+    const int per = __builtin_amdgcn_readfirstlane((rows + row_parts - 1) / row_parts);
     lo = part * per;
     hi = (lo + per < rows) ? lo + per : rows;
     if (lo > rows) lo = rows;
@@ -264,10 +289,11 @@ __device__ __forceinline__ double touch_rows(const double* first_row, int nrows,
 
 // every other block: work unit = (chunk of <= 64 items of one (channel, block) bucket) x (row range);
 // lane = item.
-__global__ __launch_bounds__(64, 3) void mp_detail_kernel(const Workspace ws, const DictDevice dict, int row_parts,
-                                                          double* touch_sink)
+__global__ __launch_bounds__(64, 3) void mp_detail_kernel(const Workspace ws, const DictDevice dict, int max_row_parts,
+                                                          int grid_hint, double* touch_sink)
 {
     const int lane = threadIdx.x;
+    const int row_parts = effective_parts((int)scalar_counter(ws.counters, 7), grid_hint, max_row_parts);
     const unsigned n_units = scalar_counter(ws.counters, 7) * (unsigned)row_parts;
     double keep = 0.0;
     // static grid-stride assignment: units cost about the same, and a shared dequeue counter saturates at
@@ -292,7 +318,7 @@ __global__ __launch_bounds__(64, 3) void mp_detail_kernel(const Workspace ws, co
         load_residual(r, ws.r + (long long)tc * N);
         double best_val;
         int best_row;
-        sweep_rows(r, as_scalar(dict.detail) + first * N, hi - lo, best_val, best_row);
+        sweep_rows(r, as_scalar(dict.detail + first * N), __builtin_amdgcn_readfirstlane(hi - lo), best_val, best_row);
         if (valid) {
             ws.cand_val[(long long)(begin + lane) * kMaxRowParts + part] = best_val;
             ws.cand_row[(long long)(begin + lane) * kMaxRowParts + part] = (best_row < 0) ? -1 : lo + best_row;
@@ -409,8 +435,11 @@ __global__ __launch_bounds__(256) void mp_fill_kernel(const Workspace ws, int cu
 // --------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void mp_finish_kernel(const Workspace ws, const DictDevice dict, const Outputs out,
                                                        const double* __restrict__ quant, int K, int step, int cur,
-                                                       int parts, int row_parts)
+                                                       int max_parts, int max_row_parts, int grid_hint)
 {
+    const int parts = effective_parts((((int)ws.counters[cur * 3 + 0] + 63) >> 6) + (((int)ws.counters[cur * 3 + 1] + 63) >> 6) +
+                                          (((int)ws.counters[cur * 3 + 2] + 63) >> 6), grid_hint, max_parts);
+    const int row_parts = effective_parts((int)ws.counters[7], grid_hint, max_row_parts);
     const int s0 = ((int)ws.counters[cur * 3 + 0] + 255) >> 8, s1 = ((int)ws.counters[cur * 3 + 1] + 255) >> 8,
               s2 = ((int)ws.counters[cur * 3 + 2] + 255) >> 8;
     __shared__ unsigned s_cnt[512];          // next step's items per block, counted per slab before going global
@@ -734,14 +763,14 @@ int enqueue_pursuit(const DictDevice& dict, const Workspace& ws, const FrameInpu
         }
         if (base_events) (void)hipEventRecord(static_cast<hipEvent_t>(base_events[2 * step]), s);
         hipLaunchKernelGGL(mp_base_kernel, dim3(clampu(max_groups * (unsigned)(parts + 1), slots)), dim3(64), 0, s, ws, dict,
-                           cur, parts, step > 0 ? 1 : 0);
+                           cur, parts, step > 0 ? 1 : 0, (int)slots);
         if (base_events) (void)hipEventRecord(static_cast<hipEvent_t>(base_events[2 * step + 1]), s);
         if (step > 0) {
             hipLaunchKernelGGL(mp_detail_kernel, dim3(clampu(max_groups * (unsigned)row_parts, slots)), dim3(64), 0, s, ws,
-                               dict, row_parts, ws.cand_val);
+                               dict, row_parts, (int)slots, ws.cand_val);
         }
         hipLaunchKernelGGL(mp_finish_kernel, dim3(clampu(max_slabs, 2048u)), dim3(256), 0, s, ws, dict, out, quant_dev, K,
-                           step, cur, parts, row_parts);
+                           step, cur, parts, row_parts, (int)slots);
         if (step + 1 < K)
             hipLaunchKernelGGL(mp_update_kernel, dim3(clampu(max_groups, 4096u)), dim3(64), 0, s, ws, dict, cur);
     }

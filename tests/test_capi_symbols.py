@@ -73,3 +73,14 @@ def test_product_tables_equal_oracle_tables(oracle):
             assert (c.quant == q).all(), (K, bpp)
             if c is not ctx:
                 c.close()
+
+
+def test_sweep_kernels_keep_scalar_dictionary_operands():
+    """Every v_mul_f64 of the sweep kernels in the shipped gfx950 code object reads the dictionary coefficient from
+    an SGPR (the s_load-fed design); a silent fallback to vector loads is a 6x slowdown."""
+    from imageexperiments_amd.build import verify_scalar_sweeps
+    rep = verify_scalar_sweeps()
+    if rep is None:
+        pytest.skip("llvm-objdump not available")
+    assert rep["mp_base_kernel"][1] == 128 and rep["mp_detail_kernel"][1] == 64
+    assert all(a == b for a, b in rep.values())
