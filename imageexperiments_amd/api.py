@@ -71,7 +71,7 @@ def load_library():
     L.mpc_calc_mp_batch.argtypes = [vp, C.c_int, _dp, _dp, C.c_int, vp, _u16p, _dp, _u32p]
     L.mpc_reserve.argtypes = [vp, C.c_longlong]
     L.mpc_kernel_timing_enable.argtypes = [vp, C.c_int]
-    L.mpc_kernel_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
+    L.mpc_kernel_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]
     _bind_bitstream(L)
     _lib = L
     return L
@@ -340,10 +340,10 @@ class CompressionContext:
         self.L.mpc_kernel_timing_enable(self.h, 1 if on else 0)
 
     def read_kernel_timing(self):
-        """-> (summed base-sweep ms, launches) since the last read; synchronises."""
-        ms, n = C.c_double(0), C.c_longlong(0)
-        _check(self.L.mpc_kernel_timing_read(self.h, C.byref(ms), C.byref(n)))
-        return ms.value, n.value
+        """-> (summed base-sweep ms, launches, ms of the union of the launch intervals) since the last read."""
+        ms, n, busy = C.c_double(0), C.c_longlong(0), C.c_double(0)
+        _check(self.L.mpc_kernel_timing_read(self.h, C.byref(ms), C.byref(n), C.byref(busy)))
+        return ms.value, n.value, busy.value
 
     def encode_image(self, rgb, quant=None):
         """compressed::encodeImage (CompressedImage.h:59): device tile encode + host entropy stage -> bytes."""

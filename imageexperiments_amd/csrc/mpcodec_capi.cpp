@@ -8,8 +8,10 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <new>
+#include <utility>
 #include <stdexcept>
 #include <vector>
 
@@ -56,10 +58,19 @@ struct mpc_context {
     double* d_quant = nullptr;
     int32_t* d_rows = nullptr;
     int32_t* d_rowoff = nullptr;
-    void* d_workspace = nullptr;      // step-synchronous pursuit state for up to ws_cap tile-channels
-    size_t ws_bytes = 0;
-    int ws_cap = 0;
-    mpc::Workspace ws{};
+    // The pursuit of a call is cut into sub-batches that run on `pipes` internal streams, each with its own
+    // workspace: the latency-bound bookkeeping kernels of one sub-batch (finish, update, bucket, fill) overlap
+    // the machine-filling sweeps of the other.  Fork/join with events on the caller's stream: still no host
+    // synchronisation, still capturable.
+    struct Pipe {
+        hipStream_t stream = nullptr;
+        hipEvent_t done = nullptr;
+        void* mem = nullptr;
+        mpc::Workspace ws{};
+    };
+    std::vector<Pipe> pipes;
+    hipEvent_t fork = nullptr;
+    int ws_cap = 0;                   // tile-channels per pipe workspace
     int base_rows_padded = 0;
     int max_waves = 0;
     int num_cus = 0;
@@ -67,10 +78,17 @@ struct mpc_context {
     bool timing = false;
     std::vector<hipEvent_t> timing_events;      // 2 per launch, grown on demand
     size_t timing_used = 0;
+    hipEvent_t timing_ref = nullptr;            // common time origin for the union of launch intervals
 };
 
 namespace {
-constexpr long long kMaxBatch = 3LL * 262144;       // tile-channels per pursuit batch (workspace is sized for it)
+constexpr long long kMaxBatch = 3LL * 262144;       // tile-channels in flight per call (the workspaces are sized for it)
+
+// tuning overrides for experiments (results never depend on them)
+int env_int(const char* name, int fallback) {
+    const char* v = std::getenv(name);
+    return (v && *v) ? std::atoi(v) : fallback;
+}
 
 mpc::DictDevice dict_device(const mpc_context* c) {
     mpc::DictDevice d{};
@@ -84,24 +102,44 @@ mpc::DictDevice dict_device(const mpc_context* c) {
     return d;
 }
 
-// grow-only workspace; allocation synchronises the device, so callers that must not (graph capture)
+// grow-only workspaces; allocation synchronises the device, so callers that must not (graph capture)
 // call mpc_reserve() first
+// how many sub-batches of a call run concurrently (measured on MI355X: 2 for a 1080p frame, 3 from ~300k
+// tile-channels up; 4 loses again)
+int pipes_for(long long tile_channels) {
+    const int forced = env_int("MPC_PIPES", 0);
+    if (forced > 0) return std::min(forced, 4);
+    if (tile_channels <= 3 * 4096) return 1;              // do not split what cannot fill the machine
+    return tile_channels >= 300000 ? 3 : 2;
+}
+
 mpc_status ensure_workspace(mpc_context* c, long long tile_channels) {
-    long long cap = tile_channels < kMaxBatch ? tile_channels : kMaxBatch;
-    cap = (cap + 767) / 768 * 768;                       // whole units (3 tile-channels) and whole 256-blocks
-    if (cap <= c->ws_cap) return MPC_OK;
-    if (c->d_workspace) {
-        if (hipDeviceSynchronize() != hipSuccess) return fail(MPC_ERR_HIP, "device synchronise failed");
-        (void)hipFree(c->d_workspace);
-        c->d_workspace = nullptr;
-        c->ws_cap = 0;
+    const int want_pipes = pipes_for(tile_channels);
+    long long total = tile_channels < kMaxBatch ? tile_channels : kMaxBatch;
+    long long cap = (total + want_pipes - 1) / want_pipes;
+    cap = (cap + 767) / 768 * 768;                                        // whole units (3 tile-channels), whole 256-blocks
+    if (cap <= c->ws_cap && static_cast<int>(c->pipes.size()) >= want_pipes) return MPC_OK;
+    if (hipDeviceSynchronize() != hipSuccess) return fail(MPC_ERR_HIP, "device synchronise failed");
+    if (!c->fork && hipEventCreateWithFlags(&c->fork, hipEventDisableTiming) != hipSuccess)
+        return fail(MPC_ERR_HIP, "event creation failed");
+    while (static_cast<int>(c->pipes.size()) < want_pipes) {
+        mpc_context::Pipe p;
+        if (hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&p.done, hipEventDisableTiming) != hipSuccess)
+            return fail(MPC_ERR_HIP, "stream/event creation failed");
+        c->pipes.push_back(p);
     }
+    if (cap < c->ws_cap) cap = c->ws_cap;
     const size_t bytes = mpc::workspace_bytes(static_cast<int>(cap), c->K);
-    hipError_t e = hipMalloc(&c->d_workspace, bytes);
-    if (e != hipSuccess) return fail(MPC_ERR_ALLOC, "workspace of %zu bytes: %s", bytes, hipGetErrorString(e));
-    c->ws_bytes = bytes;
+    for (auto& p : c->pipes) {
+        if (p.mem && cap == c->ws_cap) continue;          // already large enough
+        if (p.mem) (void)hipFree(p.mem);
+        p.mem = nullptr;
+        hipError_t e = hipMalloc(&p.mem, bytes);
+        if (e != hipSuccess) { c->ws_cap = 0; return fail(MPC_ERR_ALLOC, "workspace of %zu bytes: %s", bytes, hipGetErrorString(e)); }
+        p.ws = mpc::carve_workspace(p.mem, static_cast<int>(cap), c->K);
+    }
     c->ws_cap = static_cast<int>(cap);
-    c->ws = mpc::carve_workspace(c->d_workspace, c->ws_cap, c->K);
     return MPC_OK;
 }
 
@@ -110,19 +148,27 @@ mpc_status ensure_workspace(mpc_context* c, long long tile_channels) {
 constexpr int kBaseParts = 8;
 constexpr int kRowParts = 4;
 
-// tuning overrides for experiments (results never depend on them)
-int env_int(const char* name, int fallback) {
-    const char* v = std::getenv(name);
-    return (v && *v) ? std::atoi(v) : fallback;
-}
-
 mpc_status run_pursuit(mpc_context* c, const mpc::FrameInput& in, const mpc::Outputs& out, const double* d_quant,
                        long long total_tc, void* stream) {
     mpc_status st = ensure_workspace(c, total_tc);
     if (st != MPC_OK) return st;
     const mpc::DictDevice dict = dict_device(c);
-    for (long long begin = 0; begin < total_tc; begin += c->ws_cap) {
-        const long long n = (total_tc - begin < c->ws_cap) ? total_tc - begin : c->ws_cap;
+    hipStream_t caller = static_cast<hipStream_t>(stream);
+    // sub-batch size: an even share per pipe (whole units), at most the workspace capacity
+    const long long npipes = pipes_for(total_tc);
+    long long share = (total_tc + npipes - 1) / npipes;
+    share = (share + 767) / 768 * 768;
+    if (share > c->ws_cap) share = c->ws_cap;
+    HIP_TRY(hipEventRecord(c->fork, caller));
+    size_t used_pipes = 0;
+    long long index = 0;
+    for (long long begin = 0; begin < total_tc; begin += share, ++index) {
+        const long long n = (total_tc - begin < share) ? total_tc - begin : share;
+        auto& pipe = c->pipes[static_cast<size_t>(index % npipes)];
+        if (index < npipes) {
+            HIP_TRY(hipStreamWaitEvent(pipe.stream, c->fork, 0));
+            ++used_pipes;
+        }
         void** events = nullptr;
         if (c->timing) {
             const size_t need = c->timing_used + 2 * static_cast<size_t>(c->K);
@@ -134,10 +180,14 @@ mpc_status run_pursuit(mpc_context* c, const mpc::FrameInput& in, const mpc::Out
             events = reinterpret_cast<void**>(c->timing_events.data() + c->timing_used);
             c->timing_used = need;
         }
-        const int err = mpc::enqueue_pursuit(dict, c->ws, in, out, d_quant, c->K, begin, static_cast<int>(n),
+        const int err = mpc::enqueue_pursuit(dict, pipe.ws, in, out, d_quant, c->K, begin, static_cast<int>(n),
                                              env_int("MPC_BASE_PARTS", kBaseParts), env_int("MPC_ROW_PARTS", kRowParts),
-                                             env_int("MPC_SWEEP_WAVES", c->max_waves), stream, events);
+                                             env_int("MPC_SWEEP_WAVES", c->max_waves), pipe.stream, events);
         if (err != 0) return fail(MPC_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(err)));
+    }
+    for (size_t i = 0; i < used_pipes; ++i) {
+        HIP_TRY(hipEventRecord(c->pipes[i].done, c->pipes[i].stream));
+        HIP_TRY(hipStreamWaitEvent(caller, c->pipes[i].done, 0));
     }
     return MPC_OK;
 }
@@ -209,8 +259,14 @@ void mpc_context_destroy(mpc_context* c) {
         (void)hipFree(c->d_quant);
         (void)hipFree(c->d_rows);
         (void)hipFree(c->d_rowoff);
-        (void)hipFree(c->d_workspace);
+        for (auto& p : c->pipes) {
+            if (p.mem) (void)hipFree(p.mem);
+            if (p.stream) (void)hipStreamDestroy(p.stream);
+            if (p.done) (void)hipEventDestroy(p.done);
+        }
+        if (c->fork) (void)hipEventDestroy(c->fork);
         for (hipEvent_t e : c->timing_events) (void)hipEventDestroy(e);
+        if (c->timing_ref) (void)hipEventDestroy(c->timing_ref);
     }
     delete c;
 }
@@ -419,21 +475,47 @@ void mpc_kernel_timing_enable(mpc_context* c, int on) {
     if (!c) return;
     c->timing = on != 0;
     c->timing_used = 0;
+    if (c->timing && c->device >= 0) {
+        (void)hipSetDevice(c->device);
+        if (!c->timing_ref) (void)hipEventCreate(&c->timing_ref);
+        (void)hipDeviceSynchronize();
+        (void)hipEventRecord(c->timing_ref, nullptr);
+        (void)hipEventSynchronize(c->timing_ref);
+    }
 }
 
-mpc_status mpc_kernel_timing_read(mpc_context* c, double* total_ms, long long* launches) {
+mpc_status mpc_kernel_timing_read(mpc_context* c, double* total_ms, long long* launches, double* busy_ms) {
     if (!c || !total_ms || !launches) return fail(MPC_ERR_ARGUMENT, "null argument");
     if (c->device < 0) return fail(MPC_ERR_NO_DEVICE, "context was created without a device");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipDeviceSynchronize());
     double sum = 0.0;
+    std::vector<std::pair<float, float>> spans;
     for (size_t i = 0; i + 1 < c->timing_used; i += 2) {
-        float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, c->timing_events[i], c->timing_events[i + 1]));
-        sum += ms;
+        float a = 0.f, b = 0.f;
+        HIP_TRY(hipEventElapsedTime(&a, c->timing_ref, c->timing_events[i]));
+        HIP_TRY(hipEventElapsedTime(&b, c->timing_ref, c->timing_events[i + 1]));
+        sum += b - a;
+        spans.emplace_back(a, b);
     }
+    // launches on the internal streams overlap: the union of their intervals is the time the machine spent in
+    // this kernel
+    std::sort(spans.begin(), spans.end());
+    double busy = 0.0;
+    float lo = 0.f, hi = -1.f;
+    for (const auto& sp : spans) {
+        if (hi < lo || sp.first > hi) {
+            if (hi >= lo) busy += hi - lo;
+            lo = sp.first;
+            hi = sp.second;
+        } else if (sp.second > hi) {
+            hi = sp.second;
+        }
+    }
+    if (hi >= lo) busy += hi - lo;
     *total_ms = sum;
     *launches = static_cast<long long>(c->timing_used / 2);
+    if (busy_ms) *busy_ms = busy;
     c->timing_used = 0;
     return MPC_OK;
 }

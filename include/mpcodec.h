@@ -134,14 +134,16 @@ mpc_status mpc_calc_mp_batch(mpc_context* ctx, int channel, const double* quant_
 
 /* Pre-allocates the device workspace for calls of up to max_tiles tiles (3 tile-channels each).  The encode
  * entry points grow the workspace on demand, which synchronises the device; callers that must not synchronise
- * (stream capture) reserve first.  Larger inputs are processed in batches of 262144 tiles. */
+ * (stream capture) reserve first.  A call is cut into sub-batches that run on two internal streams (forked from and
+ * joined to the caller's stream with events); at most 262144 tiles are in flight. */
 mpc_status mpc_reserve(mpc_context* ctx, long long max_tiles);
 
 /* Live timing of the dominant kernel (the base sweep, mp_base_kernel): while enabled every launch of it is
- * bracketed by HIP events on the launch stream.  mpc_kernel_timing_read synchronises, returns the summed
- * duration and the number of launches since the last read/enable, and resets.  Measurement only. */
+ * bracketed by HIP events on the stream it is launched on.  mpc_kernel_timing_read synchronises and returns, for
+ * the launches since the last read/enable: the summed duration, their number, and (busy_ms, may be NULL) the
+ * length of the union of their intervals -- launches of the two internal streams overlap.  Measurement only. */
 void mpc_kernel_timing_enable(mpc_context* ctx, int on);
-mpc_status mpc_kernel_timing_read(mpc_context* ctx, double* total_ms, long long* launches);
+mpc_status mpc_kernel_timing_read(mpc_context* ctx, double* total_ms, long long* launches, double* busy_ms);
 
 /* ---- host entropy stage and container (stays on the host; bytes identical to the reference) ----------
  * Buffers returned through `uint8_t**` / `uint16_t**` are malloc'ed by the library: release with mpc_free. */
