@@ -88,6 +88,9 @@ def main():
     ap.add_argument("--waves", type=int, default=0, help="grid size in wave64 workgroups (0 = automatic)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-cols", type=int, default=160, help="tile columns in the CPU sample")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend; gloo + --share-device rehearses the N>1 path on a one-GPU box")
+    ap.add_argument("--share-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     args = ap.parse_args()
 
     import torch
@@ -102,10 +105,15 @@ def main():
             sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the hot path has no CPU fallback")
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL over xGMI
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL over xGMI
+        else:
+            dist.init_process_group("gloo")
 
     W, H, K, q = WORKLOADS[args.workload]
     ctx = ia.create_compression_context(K, 8, q, device=local_rank)
@@ -137,7 +145,12 @@ def main():
             ev[i][1].record(stream)
         ctx.histogram_device(d_counts.data_ptr(), d_choices.data_ptr(), tiles, d_hist.data_ptr(), stream=stream.cuda_stream)
         if world > 1:
-            dist.all_reduce(d_hist)                          # the path's only exchange
+            if args.backend == "nccl":
+                dist.all_reduce(d_hist)                      # the path's only exchange
+            else:
+                h = d_hist.cpu()
+                dist.all_reduce(h)
+                d_hist.copy_(h)
 
     def fence():
         if world > 1:
@@ -154,7 +167,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
