@@ -97,6 +97,7 @@ def _bind_bitstream(L):
     L.mpc_rle_encode.argtypes = [_u16p, C.c_size_t, C.POINTER(_u16p), C.POINTER(C.c_size_t)]
     L.mpc_rle_decode.argtypes = [_u16p, C.c_size_t, C.POINTER(_u16p), C.POINTER(C.c_size_t)]
     L.mpc_encode_image.argtypes = [vp, _u8p, C.c_int, C.c_int, _dp, C.POINTER(_u8p), C.POINTER(C.c_size_t)]
+    L.mpc_decode_tiles_device.argtypes = [vp, vp, vp, _dp, C.c_int, C.c_int, vp, vp]
     L.mpc_decode_image.argtypes = [vp, _u8p, C.c_size_t, C.POINTER(_u8p), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.mpc_psnr.argtypes = [_u8p, _u8p, C.c_int, C.c_int]
     L.mpc_psnr.restype = C.c_double

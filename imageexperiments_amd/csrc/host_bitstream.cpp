@@ -597,4 +597,26 @@ Streams assemble_streams(int width, int height, int K, int block_size, const dou
     return s;
 }
 
+bool disassemble_streams(const Streams& s, std::vector<uint16_t>& counts, std::vector<uint32_t>& choices) {
+    const int K = s.K;
+    const size_t n = s.lengths.size();
+    counts.assign(s.lengths.begin(), s.lengths.end());
+    choices.assign(n * static_cast<size_t>(K), 0);
+    std::vector<size_t> cursor(static_cast<size_t>(3 * K), 0);
+    for (size_t o = 0; o < n; ++o) {
+        const int ch = static_cast<int>(o % 3);
+        const int count = s.lengths[o];
+        if (count > K) return false;
+        for (int i = 0; i < count; ++i) {
+            const std::vector<uint16_t>& d = s.codes[2 * K * ch + 2 * i];
+            const std::vector<uint16_t>& c = s.codes[2 * K * ch + 2 * i + 1];
+            size_t& at = cursor[static_cast<size_t>(ch * K + i)];
+            if (at >= d.size() || at >= c.size()) return false;
+            choices[o * K + i] = static_cast<uint32_t>(d[at]) | (static_cast<uint32_t>(c[at]) << 16);
+            ++at;
+        }
+    }
+    return true;
+}
+
 }  // namespace mpc

@@ -112,6 +112,18 @@ int enqueue_pursuit(const DictDevice& dict, const Workspace& ws, const FrameInpu
 
 int launch_histogram(const HistParams& p, void* stream);
 
+// Decoder: FromCoeffsDynamic + RGBFromYUV for whole tiles.
+struct DecodeParams {
+    const uint16_t* counts;          // [tiles][3], tile t = tx*tiles_y + ty (the reference's visiting order)
+    const uint32_t* choices;         // [tiles][3][K]
+    const double* quant;             // [3][K] (device)
+    int K;
+    int width, height, tiles_x, tiles_y;
+    uint8_t* rgb;                    // [height][width][3] (device)
+    int* error_flag;                 // set to 1 if a record indexes outside its dynamic dictionary
+};
+int launch_decode(const DictDevice& dict, const DecodeParams& p, void* stream);
+
 // bytes of workspace needed for `cap` tile-channels and K steps
 size_t workspace_bytes(int cap, int K);
 // carve a workspace out of one device allocation of workspace_bytes(cap, K) bytes

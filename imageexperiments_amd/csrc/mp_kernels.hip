@@ -672,6 +672,81 @@ __global__ __launch_bounds__(256) void mp_histogram_kernel(const HistParams p, i
 }
 
 // --------------------------------------------------------------------------------------------------
+// decode: one wave per tile, LANE = PIXEL.  For each channel the recorded steps are replayed in order:
+// choice = running sum of the zig-zag deltas, coefficient = quant[i] * zigzagDecode(intCoeff), and every pixel
+// accumulates results[j] += basis[j] * coeff in step order (MatchingPursuit.cpp:109-128, one rounding for the
+// product, one for the sum -- no FMA).  The dynamic dictionary is resolved through the same block list as in
+// the encoder (base rows, then DetailBasis[choice] of every earlier base choice, repeats included,
+// CompressedImage.cpp:219-248).  Then RGBFromYUV (misc.cpp:28-36): round half away, clamp, store.
+// --------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void mp_decode_kernel(const DictDevice dict, const DecodeParams p)
+{
+    const int lane = threadIdx.x;
+    const long long tiles = (long long)p.tiles_x * p.tiles_y;
+    for (long long t = blockIdx.x; t < tiles; t += gridDim.x) {
+        double yuv[3];
+        for (int ch = 0; ch < 3; ++ch) {
+            const int count = p.counts[t * 3 + ch];
+            const uint32_t* rec = p.choices + (t * 3 + ch) * p.K;
+            double acc = 0.0;
+            int choice = 0;
+            for (int i = 0; i < count && i < p.K; ++i) {
+                const uint32_t r = rec[i];
+                const unsigned delta = r & 0xFFFFu, zz = r >> 16;
+                const int d = (int)((delta >> 1) ^ (0u - (delta & 1u)));
+                choice = (i > 0) ? choice + d : (int)delta;
+                const int q = (int)((zz >> 1) ^ (0u - (zz & 1u)));
+                const double coeff = p.quant[ch * p.K + i] * (double)q;
+                // locate row `choice` in the dynamic dictionary of this tile-channel; the reference builds it from
+                // ALL `count` choices before summing (FromCoeffsDynamic :111), so resolve against the full list
+                const double* row = nullptr;
+                if (choice >= 0 && choice < dict.num_base) {
+                    row = dict.base + (long long)choice * N;
+                } else if (choice >= dict.num_base) {
+                    int off = dict.num_base;
+                    int walk = 0;
+                    for (int k = 0; k < count && k < p.K; ++k) {
+                        const uint32_t rk = rec[k];
+                        const unsigned dk = rk & 0xFFFFu;
+                        walk = (k > 0) ? walk + (int)((dk >> 1) ^ (0u - (dk & 1u))) : (int)dk;
+                        if (walk >= 0 && walk < dict.num_base) {
+                            const int rows = dict.block_rows[walk];
+                            if (choice < off + rows) {
+                                row = dict.detail + ((long long)ch * dict.detail_rows + dict.block_row_off[walk] + (choice - off)) * N;
+                                break;
+                            }
+                            off += rows;
+                        }
+                    }
+                }
+                if (!row) {
+                    if (lane == 0) *p.error_flag = 1;
+                    continue;
+                }
+                const double term = row[lane] * coeff;
+                acc = acc + term;
+            }
+            yuv[ch] = acc;
+        }
+        const int tx = (int)(t / p.tiles_y), ty = (int)(t - (long long)tx * p.tiles_y);
+        const int u = tx * 8 + (lane & 7), v = ty * 8 + (lane >> 3);          // block index = dx + 8*dy
+        if (u < p.width && v < p.height) {
+            const double Y = yuv[0], U = yuv[1], V = yuv[2];
+            double rr = __builtin_round(Y + 1.13983 * V);
+            double gg = __builtin_round(Y - 0.39466 * U - 0.58060 * V);
+            double bb = __builtin_round(Y + 2.03211 * U);
+            rr = rr < 0.0 ? 0.0 : (rr > 255.0 ? 255.0 : rr);
+            gg = gg < 0.0 ? 0.0 : (gg > 255.0 ? 255.0 : gg);
+            bb = bb < 0.0 ? 0.0 : (bb > 255.0 ? 255.0 : bb);
+            uint8_t* px = p.rgb + 3 * ((long long)v * p.width + u);
+            px[0] = (uint8_t)rr;
+            px[1] = (uint8_t)gg;
+            px[2] = (uint8_t)bb;
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
 // host side: workspace carving and the per-step launch sequence
 // --------------------------------------------------------------------------------------------------
 namespace {
@@ -774,6 +849,15 @@ int enqueue_pursuit(const DictDevice& dict, const Workspace& ws, const FrameInpu
         if (step + 1 < K)
             hipLaunchKernelGGL(mp_update_kernel, dim3(clampu(max_groups, 4096u)), dim3(64), 0, s, ws, dict, cur);
     }
+    return (int)hipGetLastError();
+}
+
+int launch_decode(const DictDevice& dict, const DecodeParams& p, void* stream)
+{
+    const long long tiles = (long long)p.tiles_x * p.tiles_y;
+    unsigned blocks = (unsigned)(tiles < 16384 ? tiles : 16384);
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(mp_decode_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream, dict, p);
     return (int)hipGetLastError();
 }
 

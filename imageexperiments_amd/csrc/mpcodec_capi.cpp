@@ -58,6 +58,7 @@ struct mpc_context {
     double* d_quant = nullptr;
     int32_t* d_rows = nullptr;
     int32_t* d_rowoff = nullptr;
+    int* d_flag = nullptr;            // decode: set when a record indexes outside its dictionary
     // The pursuit of a call is cut into sub-batches that run on `pipes` internal streams, each with its own
     // workspace: the latency-bound bookkeeping kernels of one sub-batch (finish, update, bucket, fill) overlap
     // the machine-filling sweeps of the other.  Fork/join with events on the caller's stream: still no host
@@ -259,6 +260,7 @@ void mpc_context_destroy(mpc_context* c) {
         (void)hipFree(c->d_quant);
         (void)hipFree(c->d_rows);
         (void)hipFree(c->d_rowoff);
+        (void)hipFree(c->d_flag);
         for (auto& p : c->pipes) {
             if (p.mem) (void)hipFree(p.mem);
             if (p.stream) (void)hipStreamDestroy(p.stream);
@@ -677,11 +679,84 @@ mpc_status mpc_encode_image(mpc_context* c, const uint8_t* rgb, int width, int h
                                 choices.data(), bytes, nbytes);
 }
 
-// compressed::decodeImage (host in this round)
-mpc_status mpc_decode_image(const mpc_context* c, const uint8_t* bytes, size_t nbytes, uint8_t** rgb, int* width, int* height) {
+// FromCoeffsDynamic + RGBFromYUV for whole tiles on the device
+mpc_status mpc_decode_tiles_device(mpc_context* c, const uint16_t* d_counts, const mpc_basis_choice* d_choices,
+                                   const double* quant, int width, int height, uint8_t* d_rgb, void* stream) {
+    if (!c || !d_counts || !d_choices || !d_rgb) return fail(MPC_ERR_ARGUMENT, "null argument");
+    if (c->device < 0) return fail(MPC_ERR_NO_DEVICE, "context was created without a device");
+    if (width < 1 || height < 1) return fail(MPC_ERR_ARGUMENT, "bad geometry");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->d_flag) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_flag), sizeof(int)));
+    if (quant) HIP_TRY(hipMemcpyAsync(c->d_quant, quant, 3 * sizeof(double) * c->K, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(c->d_flag, 0, sizeof(int), s));
+    mpc::DecodeParams p{};
+    p.counts = d_counts;
+    p.choices = reinterpret_cast<const uint32_t*>(d_choices);
+    p.quant = c->d_quant;
+    p.K = c->K;
+    p.width = width;
+    p.height = height;
+    p.tiles_x = (width + 7) / 8;
+    p.tiles_y = (height + 7) / 8;
+    p.rgb = d_rgb;
+    p.error_flag = c->d_flag;
+    const int err = mpc::launch_decode(dict_device(c), p, stream);
+    if (err != 0) return fail(MPC_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(err)));
+    return MPC_OK;
+}
+
+// compressed::decodeImage: container parsing on the host; tile reconstruction on the device when the context
+// has one and matches the stream's K / block size, on the host otherwise
+mpc_status mpc_decode_image(const mpc_context* cc, const uint8_t* bytes, size_t nbytes, uint8_t** rgb, int* width, int* height) {
     if (!bytes || !rgb || !width || !height) return fail(MPC_ERR_ARGUMENT, "null argument");
     mpc::Streams s;
     if (!mpc::read_compressed(bytes, nbytes, s)) return fail(MPC_ERR_BITSTREAM, "Invalid input data");
+    mpc_context* c = const_cast<mpc_context*>(cc);
+    if (c && c->device >= 0 && c->K == s.K && s.block_size == 8) {
+        std::vector<uint16_t> counts;
+        std::vector<uint32_t> choices;
+        if (!mpc::disassemble_streams(s, counts, choices)) return fail(MPC_ERR_BITSTREAM, "Invalid bitstream");
+        std::vector<double> q(3 * static_cast<size_t>(s.K));
+        for (int ch = 0; ch < 3; ++ch)
+            for (int i = 0; i < s.K; ++i) q[ch * s.K + i] = static_cast<double>(s.quant[ch][i]);
+        HIP_TRY(hipSetDevice(c->device));
+        uint16_t* d_counts = nullptr;
+        uint32_t* d_choices = nullptr;
+        uint8_t* d_rgb = nullptr;
+        const size_t px = static_cast<size_t>(s.width) * s.height * 3;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_counts), counts.size() * 2);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_choices), choices.size() * 4);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_rgb), px);
+        if (e == hipSuccess) e = hipMemcpy(d_counts, counts.data(), counts.size() * 2, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(d_choices, choices.data(), choices.size() * 4, hipMemcpyHostToDevice);
+        mpc_status st = MPC_OK;
+        int flag = 0;
+        uint8_t* out = nullptr;
+        if (e == hipSuccess) {
+            // the context's device quant table is restored afterwards (decode uses the stream's header values)
+            st = mpc_decode_tiles_device(c, d_counts, reinterpret_cast<const mpc_basis_choice*>(d_choices), q.data(), s.width,
+                                         s.height, d_rgb, nullptr);
+            if (st == MPC_OK) e = hipDeviceSynchronize();
+            if (st == MPC_OK && e == hipSuccess) e = hipMemcpy(&flag, c->d_flag, sizeof(int), hipMemcpyDeviceToHost);
+            if (st == MPC_OK && e == hipSuccess) {
+                out = static_cast<uint8_t*>(std::malloc(px ? px : 1));
+                if (out) e = hipMemcpy(out, d_rgb, px, hipMemcpyDeviceToHost);
+            }
+            if (e == hipSuccess) e = hipMemcpy(c->d_quant, c->quant.data(), c->quant.size() * sizeof(double), hipMemcpyHostToDevice);
+        }
+        (void)hipFree(d_counts);
+        (void)hipFree(d_choices);
+        (void)hipFree(d_rgb);
+        if (st != MPC_OK) { std::free(out); return st; }
+        if (e != hipSuccess) { std::free(out); return fail(MPC_ERR_HIP, "HIP failure: %s", hipGetErrorString(e)); }
+        if (!out) return fail(MPC_ERR_ALLOC, "out of memory");
+        if (flag) { std::free(out); return fail(MPC_ERR_BITSTREAM, "Invalid bitstream"); }
+        *rgb = out;
+        *width = s.width;
+        *height = s.height;
+        return MPC_OK;
+    }
     mpc::Dictionary local;
     const mpc::Dictionary* dict = nullptr;
     if (c && c->block_size == s.block_size) dict = &c->dict;

@@ -25,6 +25,7 @@
  *   mpc_read_compressed       compressed::readCompressed                  CompressedImage.cpp:635
  *   mpc_encode_image          compressed::encodeImage                     CompressedImage.h:59
  *   mpc_decode_image          compressed::decodeImage                     CompressedImage.h:75
+ *   mpc_decode_tiles_device   matching::FromCoeffsDynamic per tile        MatchingPursuit.h:25, CompressedImage.cpp:797-831
  *   mpc_psnr                  compressed::calculatePSNR                   CompressedImage.h:57
  *   mpc_huffman_encode/decode huffman::huffmanEncode / huffmanDecode      Huffman.h:15-19
  *   mpc_rle_encode/decode     huffman::runLengthEncode / runLengthDecode  Huffman.h:12-13
@@ -184,8 +185,15 @@ mpc_status mpc_rle_decode(const uint16_t* data, size_t n, uint16_t** out, size_t
 mpc_status mpc_encode_image(mpc_context* ctx, const uint8_t* rgb, int width, int height, const double* quant,
                             uint8_t** bytes, size_t* nbytes);
 
-/* compressed::decodeImage (CompressedImage.h:75); ctx may be NULL (the dictionary is then rebuilt, ~1 s).
- * Host implementation in this round. */
+/* matching::FromCoeffsDynamic (MatchingPursuit.h:25) + img::RGBFromYUV for every tile of a frame on the device:
+ * records in the reference's order (tile t = tx*tiles_y + ty, as mpc_encode_tiles returns them for the whole
+ * frame), d_rgb = height*width*3 bytes.  quant: host [3*K] or NULL = context tables.  Asynchronous. */
+mpc_status mpc_decode_tiles_device(mpc_context* ctx, const uint16_t* d_counts, const mpc_basis_choice* d_choices,
+                                   const double* quant, int width, int height, uint8_t* d_rgb, void* stream);
+
+/* compressed::decodeImage (CompressedImage.h:75).  The container is parsed on the host; the tiles are
+ * reconstructed on the device when ctx has one and matches the stream's K (block size 8), otherwise on the host;
+ * ctx may be NULL (host, the dictionary is then rebuilt, ~1 s). */
 mpc_status mpc_decode_image(const mpc_context* ctx, const uint8_t* bytes, size_t nbytes, uint8_t** rgb, int* width,
                             int* height);
 
