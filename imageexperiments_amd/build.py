@@ -13,7 +13,7 @@ SOURCES = ["host_dictionary.cpp", "host_bitstream.cpp", "host_codec.cpp", "mp_ke
 HEADERS = ["host_dictionary.h", "host_bitstream.h", "host_codec.h", "mp_device.h", os.path.join("..", "..", "include", "mpcodec.h")]
 # -ffp-contract=off: host and device must round every mul and add separately (the reference is built
 # with MSVC /fp:precise and the integer outputs depend on it).
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-pthread",
          "-Wall", "-Wno-unused-result"]
 
 

@@ -2,8 +2,11 @@
 #include "host_bitstream.h"
 
 #include <algorithm>
+#include <atomic>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <thread>
 
 namespace mpc {
 
@@ -493,6 +496,36 @@ std::vector<uint16_t> dc_difference(const std::vector<uint16_t>& v) {       // :
 }
 }  // namespace
 
+namespace {
+// The 1 + 6K streams of a container are coded independently and only concatenated bit-wise afterwards, so
+// they are coded on a small thread pool (the reference is single-threaded; the bytes do not depend on it).
+int host_threads() {
+    if (const char* v = std::getenv("MPC_HOST_THREADS")) {
+        const int n = std::atoi(v);
+        if (n > 0) return n;
+    }
+    const unsigned hc = std::thread::hardware_concurrency();
+    return static_cast<int>(hc == 0 ? 1 : (hc > 16 ? 16 : hc));
+}
+
+template <class F>
+void parallel_for(int n, F&& body) {
+    const int workers = std::min(host_threads(), n);
+    if (workers <= 1) {
+        for (int i = 0; i < n; ++i) body(i);
+        return;
+    }
+    std::atomic<int> next{0};
+    std::vector<std::thread> pool;
+    pool.reserve(static_cast<size_t>(workers));
+    for (int w = 0; w < workers; ++w)
+        pool.emplace_back([&]() {
+            for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) body(i);
+        });
+    for (auto& t : pool) t.join();
+}
+}  // namespace
+
 std::vector<uint8_t> write_compressed(const Streams& s) {
     const int K = s.K;
     BitWriter out;
@@ -503,21 +536,28 @@ std::vector<uint8_t> write_compressed(const Streams& s) {
     out.put(static_cast<uint8_t>(s.block_size), 8);
     for (int ch = 0; ch < 3; ++ch)
         for (int i = 0; i < K; ++i) out.put(s.quant[ch][i], 16);
-    write_huffman_or_golomb(s.lengths.data(), s.lengths.size(), out);
-    for (int i = 0; i < 6 * K; ++i) {
+    std::vector<BitWriter> parts(static_cast<size_t>(6 * K + 1));
+    parallel_for(6 * K + 1, [&](int job) {
+        BitWriter& w = parts[static_cast<size_t>(job)];
+        if (job == 0) {
+            write_huffman_or_golomb(s.lengths.data(), s.lengths.size(), w);
+            return;
+        }
+        const int i = job - 1;
         const bool dc = (i == 1 || i == 2 * K + 1 || i == 4 * K + 1);
         const std::vector<uint16_t> diffed = dc ? dc_difference(s.codes[i]) : std::vector<uint16_t>();
         const std::vector<uint16_t>& stream = dc ? diffed : s.codes[i];
         const std::vector<uint16_t> packed = rle_encode(stream.data(), stream.size());
         if (packed.size() + 4 < stream.size()) {                 // :450
-            out.put(1, 1);
-            out.put(static_cast<uint32_t>(packed.size()), 32);
-            write_huffman_or_golomb(packed.data(), packed.size(), out);
+            w.put(1, 1);
+            w.put(static_cast<uint32_t>(packed.size()), 32);
+            write_huffman_or_golomb(packed.data(), packed.size(), w);
         } else {
-            out.put(0, 1);
-            write_huffman_or_golomb(stream.data(), stream.size(), out);
+            w.put(0, 1);
+            write_huffman_or_golomb(stream.data(), stream.size(), w);
         }
-    }
+    });
+    for (const BitWriter& w : parts) out.append(w);
     return out.bytes();
 }
 
@@ -586,14 +626,20 @@ Streams assemble_streams(int width, int height, int K, int block_size, const dou
             s.codes[2 * K * ch + 2 * i].reserve(sizes[ch * K + i]);
             s.codes[2 * K * ch + 2 * i + 1].reserve(sizes[ch * K + i]);
         }
-    for (size_t o = 0; o < 3 * tiles; ++o) {
-        const int ch = static_cast<int>(o % 3);
-        const uint32_t* rec = choices + o * K;
-        for (int i = 0; i < counts[o]; ++i) {
-            s.codes[2 * K * ch + 2 * i].push_back(static_cast<uint16_t>(rec[i] & 0xFFFFu));
-            s.codes[2 * K * ch + 2 * i + 1].push_back(static_cast<uint16_t>(rec[i] >> 16));
+    // one job per (channel, step): each fills its own pair of streams by scanning that channel's counts
+    parallel_for(3 * K, [&](int job) {
+        const int ch = job / K, i = job - ch * K;
+        std::vector<uint16_t>& d = s.codes[2 * K * ch + 2 * i];
+        std::vector<uint16_t>& c = s.codes[2 * K * ch + 2 * i + 1];
+        for (size_t t = 0; t < tiles; ++t) {
+            const size_t o = 3 * t + static_cast<size_t>(ch);
+            if (counts[o] > i) {
+                const uint32_t rec = choices[o * K + i];
+                d.push_back(static_cast<uint16_t>(rec & 0xFFFFu));
+                c.push_back(static_cast<uint16_t>(rec >> 16));
+            }
         }
-    }
+    });
     return s;
 }
 
