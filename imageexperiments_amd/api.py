@@ -23,7 +23,8 @@ class MpcError(RuntimeError):
 
 
 def library_path():
-    return os.path.join(HERE, "lib", "libmpcodec.so")
+    """In-tree library; MPCODEC_LIB selects another build of it (A/B timing of two kernel versions in one run)."""
+    return os.environ.get("MPCODEC_LIB") or os.path.join(HERE, "lib", "libmpcodec.so")
 
 
 _lib = None

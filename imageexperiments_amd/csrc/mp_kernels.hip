@@ -58,67 +58,65 @@ __device__ __forceinline__ scalar_f64_ptr as_scalar(const double* p)
 }  // namespace
 
 // --------------------------------------------------------------------------------------------------
-// init: one thread per tile-channel.  Gathers the 8x8 tile (zero outside the image), converts to the
-// channel's YUV component (misc.cpp:12-21) and resets the pursuit state.
+// init.  Tile mode: one wave per tile, LANE = PIXEL (block index dx + 8*dy): the pixel is read once, converted
+// (misc.cpp:12-21) and the three channel residuals are written as three coalesced 512-byte rows; lane 0 resets
+// the three tile-channels' pursuit state.  Vector mode (CalcMPDynamic on caller vectors): one wave per vector.
+// Block 0 also resets the batch counters.
 // --------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void mp_init_kernel(const Workspace ws, const FrameInput in, long long tc_begin, int n)
+__global__ __launch_bounds__(64) void mp_init_kernel(const Workspace ws, const FrameInput in, long long tc_begin, int n)
 {
-    const int tc = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x;
+    const bool vec = in.vec_in != nullptr;
     if (blockIdx.x == 0) {
-        for (int b = threadIdx.x; b < kNumBuckets; b += blockDim.x) {
+        for (int b = lane; b < kNumBuckets; b += 64) {
             ws.bucket_count[0][b] = 0;
             ws.bucket_count[1][b] = 0;
         }
-        if (threadIdx.x == 0) {
-            const bool vec = in.vec_in != nullptr;
-            for (int c = 0; c < 3; ++c) {
-                ws.counters[c] = vec ? (c == in.vec_channel ? (unsigned)n : 0u) : (unsigned)(n / 3);
-                ws.counters[3 + c] = 0;
-                ws.counters[6 + c] = 0;                      // chunk cursor, chunk count, item count
-            }
+        if (lane < 3) {
+            ws.counters[lane] = vec ? (lane == in.vec_channel ? (unsigned)n : 0u) : (unsigned)(n / 3);
+            ws.counters[3 + lane] = 0;
+            ws.counters[6 + lane] = 0;                       // chunk cursor, chunk count, item count
         }
     }
-    if (tc >= n) return;
-    const long long gtc = tc_begin + tc;
-    double* r = ws.r + (long long)tc * N;
-    int ch, list_pos;
-    if (in.vec_in) {
-        ch = in.vec_channel;
-        list_pos = tc;
-        const double* v = in.vec_in + gtc * N;
-        for (int j = 0; j < N; ++j) r[j] = v[j];
-    } else {
-        const long long unit = gtc / 3;
-        ch = (int)(gtc - unit * 3);
-        list_pos = tc / 3;                                   // batches start on a unit boundary
+    const int per_wave = vec ? 1 : 3;                        // tile-channels handled by one wave
+    const int work = (n + per_wave - 1) / per_wave;
+    for (int w = blockIdx.x; w < work; w += gridDim.x) {
+        const int tc0 = w * per_wave;
+        const long long gtc0 = tc_begin + tc0;
+        if (vec) {
+            ws.r[(long long)tc0 * N + lane] = in.vec_in[gtc0 * N + lane];
+            if (lane == 0) {
+                ws.prev_id[tc0] = 0; ws.nblk[tc0] = 0; ws.extra_rows[tc0] = 0; ws.swept[tc0] = 0;
+                ws.out_index[tc0] = (int)((unsigned)gtc0 | ((unsigned)in.vec_channel << 30));
+                ws.act[0][in.vec_channel][tc0] = tc0;
+            }
+            continue;
+        }
+        const long long unit = gtc0 / 3;                     // batches start on a unit boundary
         const int tiles_per_frame = in.tiles_x * in.tile_rows;
         const int frame = (int)(unit / tiles_per_frame);
         const int tile = (int)(unit - (long long)frame * tiles_per_frame);
         const int tx = tile / in.tile_rows;
         const int ty = in.tile_row_begin + (tile - tx * in.tile_rows);
-        const uint8_t* frame_rgb = in.rgb + (long long)frame * in.frame_stride;
-        const int x0 = tx * 8, y0 = ty * 8;
-        for (int dy = 0; dy < 8; ++dy) {
-            const int v = y0 + dy;
-            for (int dx = 0; dx < 8; ++dx) {
-                const int u = x0 + dx;
-                double val = 0.0;                                       // zero fill outside (CompressedImage.cpp:548-552)
-                if (u < in.width && v < in.height) {
-                    const uint8_t* px = frame_rgb + (long long)v * in.row_stride + 3 * u;
-                    const double red = (double)px[0], green = (double)px[1], blue = (double)px[2];
-                    const double Y = (W_R * red + W_G * green + W_B * blue);
-                    val = (ch == 0) ? Y : ((ch == 1) ? (U_SCALE * (blue - Y)) : (V_SCALE * (red - Y)));
-                }
-                r[dx + 8 * dy] = val;
-            }
+        const int u = tx * 8 + (lane & 7), v = ty * 8 + (lane >> 3);
+        double Y = 0.0, U = 0.0, V = 0.0;                    // zero fill outside (CompressedImage.cpp:548-552)
+        if (u < in.width && v < in.height) {
+            const uint8_t* px = in.rgb + (long long)frame * in.frame_stride + (long long)v * in.row_stride + 3 * u;
+            const double red = (double)px[0], green = (double)px[1], blue = (double)px[2];
+            Y = (W_R * red + W_G * green + W_B * blue);
+            U = (U_SCALE * (blue - Y));
+            V = (V_SCALE * (red - Y));
+        }
+        ws.r[(long long)(tc0 + 0) * N + lane] = Y;
+        ws.r[(long long)(tc0 + 1) * N + lane] = U;
+        ws.r[(long long)(tc0 + 2) * N + lane] = V;
+        if (lane < 3) {
+            const int tc = tc0 + lane;
+            ws.prev_id[tc] = 0; ws.nblk[tc] = 0; ws.extra_rows[tc] = 0; ws.swept[tc] = 0;
+            ws.out_index[tc] = (int)((unsigned)(gtc0 + lane) | ((unsigned)lane << 30));   // record index | channel << 30
+            ws.act[0][lane][tc0 / 3] = tc;
         }
     }
-    ws.prev_id[tc] = 0;
-    ws.nblk[tc] = 0;
-    ws.extra_rows[tc] = 0;
-    ws.swept[tc] = 0;
-    ws.out_index[tc] = (int)((unsigned)gtc | ((unsigned)ch << 30));    // record index in the low 30 bits, channel on top
-    ws.act[0][ch][list_pos] = tc;
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -827,9 +825,8 @@ int enqueue_pursuit(const DictDevice& dict, const Workspace& ws, const FrameInpu
     const unsigned max_groups = lists * (unsigned)((per_list + 63) / 64);
     const unsigned max_slabs = lists * (unsigned)((per_list + 255) / 256);
     const unsigned slots = (unsigned)(sweep_waves > 0 ? sweep_waves : 3072);
-    const unsigned blocks_n = (unsigned)((n + 255) / 256);
     auto clampu = [](unsigned v, unsigned hi) { return v < hi ? (v ? v : 1u) : hi; };
-    hipLaunchKernelGGL(mp_init_kernel, dim3(blocks_n), dim3(256), 0, s, ws, in, tc_begin, n);
+    hipLaunchKernelGGL(mp_init_kernel, dim3(clampu((unsigned)((n + 2) / 3), 16384u)), dim3(64), 0, s, ws, in, tc_begin, n);
     for (int step = 0; step < K; ++step) {
         const int cur = step & 1;
         if (step > 0) {
