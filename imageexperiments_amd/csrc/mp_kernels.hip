@@ -810,9 +810,12 @@ Workspace carve_workspace(void* device_mem, int cap, int K) { return carve(stati
 
 int enqueue_pursuit(const DictDevice& dict, const Workspace& ws, const FrameInput& in, const Outputs& out,
                     const double* quant_dev, int K, long long tc_begin, int n, int parts, int row_parts, int sweep_waves,
-                    void* stream_, void** base_events)
+                    void* stream_, void** base_events, void* side_stream_, void* fork_event_, void* join_event_)
 {
     hipStream_t s = static_cast<hipStream_t>(stream_);
+    hipStream_t side = static_cast<hipStream_t>(side_stream_);
+    hipEvent_t ev_fork = static_cast<hipEvent_t>(fork_event_), ev_join = static_cast<hipEvent_t>(join_event_);
+    const bool forked = side != nullptr && ev_fork != nullptr && ev_join != nullptr;
     if (n < 1 || n > ws.cap) return (int)hipErrorInvalidValue;
     if (parts < 1) parts = 1;
     if (parts > kMaxParts) parts = kMaxParts;
@@ -829,17 +832,33 @@ int enqueue_pursuit(const DictDevice& dict, const Workspace& ws, const FrameInpu
     hipLaunchKernelGGL(mp_init_kernel, dim3(clampu((unsigned)((n + 2) / 3), 16384u)), dim3(64), 0, s, ws, in, tc_begin, n);
     for (int step = 0; step < K; ++step) {
         const int cur = step & 1;
+        // The detail branch of a step (bucket -> fill -> detail sweep) and its base sweep are independent: both only
+        // read the residuals and the active lists.  With a side stream they run concurrently, so the detail units
+        // fill the tail of the base sweep's last round instead of waiting for it.
+        hipStream_t ds = (forked && step > 0) ? side : s;
         if (step > 0) {
-            hipLaunchKernelGGL(mp_bucket_kernel, dim3(1), dim3(1024), 0, s, ws, step & 1);
-            hipLaunchKernelGGL(mp_fill_kernel, dim3(clampu(max_slabs, 2048u)), dim3(256), 0, s, ws, cur);
+            if (forked) {
+                (void)hipEventRecord(ev_fork, s);
+                (void)hipStreamWaitEvent(side, ev_fork, 0);
+            }
+            hipLaunchKernelGGL(mp_bucket_kernel, dim3(1), dim3(1024), 0, ds, ws, step & 1);
+            hipLaunchKernelGGL(mp_fill_kernel, dim3(clampu(max_slabs, 2048u)), dim3(256), 0, ds, ws, cur);
+            if (forked)
+                hipLaunchKernelGGL(mp_detail_kernel, dim3(clampu(max_groups * (unsigned)row_parts, slots)), dim3(64), 0, ds, ws,
+                                   dict, row_parts, (int)slots, ws.cand_val);
         }
         if (base_events) (void)hipEventRecord(static_cast<hipEvent_t>(base_events[2 * step]), s);
         hipLaunchKernelGGL(mp_base_kernel, dim3(clampu(max_groups * (unsigned)(parts + 1), slots)), dim3(64), 0, s, ws, dict,
                            cur, parts, step > 0 ? 1 : 0, (int)slots);
         if (base_events) (void)hipEventRecord(static_cast<hipEvent_t>(base_events[2 * step + 1]), s);
         if (step > 0) {
-            hipLaunchKernelGGL(mp_detail_kernel, dim3(clampu(max_groups * (unsigned)row_parts, slots)), dim3(64), 0, s, ws,
-                               dict, row_parts, (int)slots, ws.cand_val);
+            if (forked) {
+                (void)hipEventRecord(ev_join, side);
+                (void)hipStreamWaitEvent(s, ev_join, 0);
+            } else {
+                hipLaunchKernelGGL(mp_detail_kernel, dim3(clampu(max_groups * (unsigned)row_parts, slots)), dim3(64), 0, s, ws,
+                                   dict, row_parts, (int)slots, ws.cand_val);
+            }
         }
         hipLaunchKernelGGL(mp_finish_kernel, dim3(clampu(max_slabs, 2048u)), dim3(256), 0, s, ws, dict, out, quant_dev, K,
                            step, cur, parts, row_parts, (int)slots);

@@ -65,7 +65,8 @@ struct mpc_context {
     // synchronisation, still capturable.
     struct Pipe {
         hipStream_t stream = nullptr;
-        hipEvent_t done = nullptr;
+        hipStream_t side = nullptr;        // each step's detail branch runs here, beside the base sweep
+        hipEvent_t done = nullptr, fork = nullptr, join = nullptr;
         void* mem = nullptr;
         mpc::Workspace ws{};
     };
@@ -126,7 +127,10 @@ mpc_status ensure_workspace(mpc_context* c, long long tile_channels) {
     while (static_cast<int>(c->pipes.size()) < want_pipes) {
         mpc_context::Pipe p;
         if (hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&p.done, hipEventDisableTiming) != hipSuccess)
+            hipStreamCreateWithFlags(&p.side, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&p.done, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&p.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&p.join, hipEventDisableTiming) != hipSuccess)
             return fail(MPC_ERR_HIP, "stream/event creation failed");
         c->pipes.push_back(p);
     }
@@ -183,7 +187,8 @@ mpc_status run_pursuit(mpc_context* c, const mpc::FrameInput& in, const mpc::Out
         }
         const int err = mpc::enqueue_pursuit(dict, pipe.ws, in, out, d_quant, c->K, begin, static_cast<int>(n),
                                              env_int("MPC_BASE_PARTS", kBaseParts), env_int("MPC_ROW_PARTS", kRowParts),
-                                             env_int("MPC_SWEEP_WAVES", c->max_waves), pipe.stream, events);
+                                             env_int("MPC_SWEEP_WAVES", c->max_waves), pipe.stream, events,
+                                             env_int("MPC_SIDE", 0) ? pipe.side : nullptr, pipe.fork, pipe.join);
         if (err != 0) return fail(MPC_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(err)));
     }
     for (size_t i = 0; i < used_pipes; ++i) {
@@ -264,7 +269,10 @@ void mpc_context_destroy(mpc_context* c) {
         for (auto& p : c->pipes) {
             if (p.mem) (void)hipFree(p.mem);
             if (p.stream) (void)hipStreamDestroy(p.stream);
+            if (p.side) (void)hipStreamDestroy(p.side);
             if (p.done) (void)hipEventDestroy(p.done);
+            if (p.fork) (void)hipEventDestroy(p.fork);
+            if (p.join) (void)hipEventDestroy(p.join);
         }
         if (c->fork) (void)hipEventDestroy(c->fork);
         for (hipEvent_t e : c->timing_events) (void)hipEventDestroy(e);

@@ -56,7 +56,7 @@ __device__ __forceinline__ void load16(double (&g)[16], cptr_t p) {
     __builtin_amdgcn_sched_barrier(0);
 
 __global__ __launch_bounds__(64) void sweep_pipe(const double* __restrict__ base_g, int natoms, int wrap, double* outv,
-                                                 unsigned long long* cycles)
+                                                 unsigned long long* cycles, int desync)
 {
     double r[64];
 #pragma unroll
@@ -69,8 +69,9 @@ __global__ __launch_bounds__(64) void sweep_pipe(const double* __restrict__ base
     double ga[16], gb[16];
     load16(ga, base);
     for (int a = 0; a < natoms; a++) {
-        cptr_t row = base + (size_t)(a % wrap) * 64;
-        cptr_t nxt = base + (size_t)((a + 1) % wrap) * 64;
+        const int shift = desync ? (int)(blockIdx.x * 37u) : 0;      // desync: every wave walks the rows from its own offset
+        cptr_t row = base + (size_t)((a + shift) % wrap) * 64;
+        cptr_t nxt = base + (size_t)((a + 1 + shift) % wrap) * 64;
         double tot = 0.0;
         MAC_GROUP(ga, gb, 0, row + 16)
         MAC_GROUP(gb, ga, 16, row + 32)
@@ -86,19 +87,19 @@ __global__ __launch_bounds__(64) void sweep_pipe(const double* __restrict__ base
     if (threadIdx.x == 0 && blockIdx.x == 7) { cycles[1] = st1 - st0; cycles[2] = rt1 - rt0; }   // shader clocks vs 100 MHz ticks
 }
 
-void run_pipe(const double* d_base, int natoms, int wrap, int waves, double* d_out, unsigned long long* d_cyc)
+void run_pipe(const double* d_base, int natoms, int wrap, int waves, double* d_out, unsigned long long* d_cyc, int desync = 0)
 {
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(sweep_pipe, dim3(waves), dim3(64), 0, 0, d_base, natoms, wrap, d_out, d_cyc);
+    hipLaunchKernelGGL(sweep_pipe, dim3(waves), dim3(64), 0, 0, d_base, natoms, wrap, d_out, d_cyc, desync);
     hipMemset(d_cyc, 0, 8);
     hipEventRecord(e0);
-    hipLaunchKernelGGL(sweep_pipe, dim3(waves), dim3(64), 0, 0, d_base, natoms, wrap, d_out, d_cyc);
+    hipLaunchKernelGGL(sweep_pipe, dim3(waves), dim3(64), 0, 0, d_base, natoms, wrap, d_out, d_cyc, desync);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     unsigned long long cyc[3]; hipMemcpy(cyc, d_cyc, 24, hipMemcpyDeviceToHost);
-    printf("PIPE    waves=%5d wrap=%4d atoms=%d : %.3f ms, %.0f clk/atom/wave (ideal 512), MAC-lanes/s = %.2f T, shader clock %.0f MHz\n", waves, wrap,
+    printf("PIPE%s waves=%5d wrap=%4d atoms=%d : %.3f ms, %.0f clk/atom/wave (ideal 512), MAC-lanes/s = %.2f T, shader clock %.0f MHz\n", desync ? "(desync)" : "        ", waves, wrap,
            natoms, ms, (double)cyc[0] / waves / natoms, (double)waves * 64 * 64.0 * natoms / (ms * 1e-3) / 1e12,
            cyc[2] ? 100.0 * (double)cyc[1] / (double)cyc[2] : 0.0);
 }
@@ -130,9 +131,10 @@ int main()
     double* d_base; double* d_out; unsigned long long* d_cyc;
     hipMalloc(&d_base, h.size() * 8); hipMemcpy(d_base, h.data(), h.size() * 8, hipMemcpyHostToDevice);
     hipMalloc(&d_out, 8192 * 64 * 8); hipMalloc(&d_cyc, 64);
-    const int natoms = 20400;
+    const int natoms = 5100;
     for (int wrap : {510, 16}) {
-        for (int waves : {256, 1024, 2048, 3072}) run_pipe(d_base, natoms, wrap, waves, d_out, d_cyc);
+        for (int waves : {2048, 3072}) run_pipe(d_base, natoms, wrap, waves, d_out, d_cyc);
+        for (int waves : {2048, 3072}) run_pipe(d_base, natoms, wrap, waves, d_out, d_cyc, 1);
 
     }
     return 0;
