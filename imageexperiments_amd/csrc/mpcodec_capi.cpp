@@ -84,12 +84,18 @@ struct mpc_context {
 };
 
 namespace {
-constexpr long long kMaxBatch = 3LL * 262144;       // tile-channels in flight per call (the workspaces are sized for it)
+constexpr long long kMaxBatchDefault = 3LL * 262144;   // tile-channels in flight per call (the workspaces are sized for it)
 
 // tuning overrides for experiments (results never depend on them)
 int env_int(const char* name, int fallback) {
     const char* v = std::getenv(name);
     return (v && *v) ? std::atoi(v) : fallback;
+}
+
+// MPC_MAX_BATCH_TILES shrinks the in-flight limit (tests use it to exercise the multi-batch path on small frames)
+long long max_batch() {
+    const int tiles = env_int("MPC_MAX_BATCH_TILES", 0);
+    return tiles > 0 ? 3LL * ((tiles + 255) / 256 * 256) : kMaxBatchDefault;
 }
 
 mpc::DictDevice dict_device(const mpc_context* c) {
@@ -117,6 +123,7 @@ int pipes_for(long long tile_channels) {
 
 mpc_status ensure_workspace(mpc_context* c, long long tile_channels) {
     const int want_pipes = pipes_for(tile_channels);
+    const long long kMaxBatch = max_batch();
     long long total = tile_channels < kMaxBatch ? tile_channels : kMaxBatch;
     long long cap = (total + want_pipes - 1) / want_pipes;
     cap = (cap + 767) / 768 * 768;                                        // whole units (3 tile-channels), whole 256-blocks

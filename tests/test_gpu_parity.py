@@ -271,3 +271,53 @@ def test_device_decoder_rejects_out_of_range_records(gpu, ctx8, oracle):
     with pytest.raises(ia.MpcError) as e:
         ia.decode_image(blob, ctx8)
     assert e.value.status == ia.api.MPC_ERR_BITSTREAM
+
+
+def test_multi_batch_path_equals_single_batch(gpu, oracle, monkeypatch):
+    """Inputs larger than the in-flight limit are processed as several sub-batches on the internal streams (the 8K
+    config does this for real); forced here with a 256-tile limit on a 2000-tile frame and checked against the oracle."""
+    import imageexperiments_amd as ia
+    monkeypatch.setenv("MPC_MAX_BATCH_TILES", "256")
+    monkeypatch.setenv("MPC_PIPES", "3")
+    rgb = oracle.synth_frame(400, 320, 77)            # 50 x 40 tiles -> 8 sub-batches over 3 pipes
+    ctx = ia.create_compression_context(8, 8, 3.5, device=0)
+    octx = oracle.OracleContext(8, 8, 3.5)
+    _compare(ctx.encode_tiles(rgb), octx.encode_tiles(rgb), 8)
+    ctx.close()
+
+
+@pytest.mark.parametrize("workload", ["raise", "8k"])
+def test_full_size_big_frames_sampled_against_oracle(gpu, oracle, workload):
+    """BASELINE configs 3 and 5 at full size (4928x3264 K=32, 7680x4320 K=16; quality 3.5): tile columns sampled
+    across the frame equal the oracle exactly; all records are self-consistent (swept rows follow from records)."""
+    import bench
+    import imageexperiments_amd as ia
+    W, H, K, q = bench.WORKLOADS[workload]
+    rgb = bench.synth_frame(W, H, 12345)
+    ctx = ia.create_compression_context(K, 8, q, device=0)
+    counts, choices, energy, swept = ctx.encode_tiles(rgb)
+    tiles_x, tiles_y = (W + 7) // 8, (H + 7) // 8
+    assert counts.shape[0] == tiles_x * tiles_y
+    octx = oracle.OracleContext(K, 8, q)
+    for tx in (0, tiles_x // 2 + 3, tiles_x - 1):
+        oc, od, ok, oe, os_ = octx.encode_tiles(rgb, tx_begin=tx, tx_end=tx + 1)
+        sl = slice(tx * tiles_y, (tx + 1) * tiles_y)
+        assert (counts[sl] == oc[sl]).all()
+        valid = np.arange(K)[None, None, :] <= np.minimum(oc[sl][:, :, None], K - 1)
+        assert (choices["deltaId"][sl][valid] == od[sl][valid]).all()
+        assert (choices["intCoeff"][sl][valid] == ok[sl][valid]).all()
+        assert (swept[sl] == os_[sl]).all()
+        assert (energy[sl].view(np.uint64) == oe[sl].view(np.uint64)).all()
+    assert counts.max() <= K
+    ctx.close()
+
+
+@pytest.mark.parametrize("bpp", [2.0, 2.5, 3.0, 4.0, 5.0, 6.0])
+def test_quality_sweep_on_a_crop_bytes_equal_oracle(gpu, oracle, bpp):
+    """BASELINE config 3 sweeps quality 2.0 .. 6.0: whole-container byte identity on a 256x192 crop per quality."""
+    import bench
+    import imageexperiments_amd as ia
+    rgb = np.ascontiguousarray(bench.synth_frame(4928, 3264, 12345)[1000:1192, 2000:2256])
+    ctx = ia.create_compression_context(32, 8, bpp, device=0)
+    assert ctx.encode_image(rgb) == oracle.OracleContext(32, 8, bpp).encode_image(rgb)
+    ctx.close()
