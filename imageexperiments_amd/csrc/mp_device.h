@@ -55,7 +55,7 @@ struct Workspace {
     int* nblk;                       // [cap] entries in blk_list
     int* extra_rows;                 // [cap] rows appended after the base part (duplicates included)
     unsigned* swept;                 // [cap]
-    uint16_t* blk_list;              // [cap][32] chosen base atoms in order, bit 15 = repeat of an earlier entry
+    uint16_t* blk_list;              // [cap][32] chosen base atoms in order: bits 0-8 atom, 9-14 rows of its block, 15 = repeat
     int* item_slot;                  // [cap][32] bucket slot of each blk_list entry for the current step
     int* out_index;                  // [cap] record index in the low 30 bits, channel in the top 2
     int* act[2][3];                  // [cap] active tile-channels per channel (ping-pong)

@@ -155,6 +155,14 @@ __device__ __forceinline__ void sweep_rows(const double (&r)[N], scalar_f64_ptr 
     }
 }
 
+// Block-list entry (u16): bits 0-8 chosen base atom (= detail block), bits 9-14 rows of that block (62 | 63), bit 15
+// = repeat of an earlier entry.  Carrying the row count saves the finish kernel a dependent gather per entry.
+__device__ __forceinline__ int entry_block(unsigned e) { return (int)(e & 0x1FFu); }
+__device__ __forceinline__ int entry_rows(unsigned e) { return (int)((e >> 9) & 0x3Fu); }
+__device__ __forceinline__ bool entry_repeat(unsigned e) { return (e & 0x8000u) != 0; }
+__device__ __forceinline__ bool entry_is_item(unsigned e) { return !entry_repeat(e) && entry_block(e) != 0; }   // bucketed sweep
+__device__ __forceinline__ bool entry_is_first_block0(unsigned e) { return !entry_repeat(e) && entry_block(e) == 0; }
+
 __device__ __forceinline__ unsigned scalar_counter(const unsigned* counters, int i)
 {
     return ((scalar_u32_ptr)(uintptr_t)counters)[i];
@@ -245,7 +253,7 @@ __global__ __launch_bounds__(64, 3) void mp_base_kernel(const Workspace ws, cons
             if (valid) {
                 const int nb = ws.nblk[tc];
                 for (int i = 0; i < nb; ++i)
-                    if (ws.blk_list[(long long)tc * kMaxDeviceK + i] == 0) has0 = true;     // first occurrence of block 0
+                    if (entry_is_first_block0(ws.blk_list[(long long)tc * kMaxDeviceK + i])) has0 = true;
             }
             if (!__ballot(has0)) continue;
             double r[N];
@@ -399,8 +407,8 @@ __global__ __launch_bounds__(256) void mp_fill_kernel(const Workspace ws, int cu
             nb = ws.nblk[tc];
             for (int i = 0; i < nb; ++i) {
                 const unsigned e = ws.blk_list[(long long)tc * kMaxDeviceK + i];
-                if (e == 0 || (e & 0x8000u)) continue;
-                ws.item_slot[(long long)tc * kMaxDeviceK + i] = (int)atomicAdd(&s_cnt[e], 1u);   // rank within the slab
+                if (!entry_is_item(e)) continue;
+                ws.item_slot[(long long)tc * kMaxDeviceK + i] = (int)atomicAdd(&s_cnt[entry_block(e)], 1u);   // rank within the slab
             }
         }
         __syncthreads();
@@ -416,8 +424,8 @@ __global__ __launch_bounds__(256) void mp_fill_kernel(const Workspace ws, int cu
         if (valid) {
             for (int i = 0; i < nb; ++i) {
                 const unsigned e = ws.blk_list[(long long)tc * kMaxDeviceK + i];
-                if (e == 0 || (e & 0x8000u)) continue;
-                const unsigned slot = s_base[e] + (unsigned)ws.item_slot[(long long)tc * kMaxDeviceK + i];
+                if (!entry_is_item(e)) continue;
+                const unsigned slot = s_base[entry_block(e)] + (unsigned)ws.item_slot[(long long)tc * kMaxDeviceK + i];
                 ws.items[slot] = tc;
                 ws.item_slot[(long long)tc * kMaxDeviceK + i] = (int)slot;
             }
@@ -465,9 +473,9 @@ __global__ __launch_bounds__(256) void mp_finish_kernel(const Workspace ws, cons
     int off = dict.num_base;
     for (int i = 0; i < nb; ++i) {
         const unsigned e = ws.blk_list[(long long)tc * kMaxDeviceK + i];
-        const int blk = (int)(e & 0x7FFFu);
-        const int rows = dict.block_rows[blk];
-        if (!(e & 0x8000u)) {               // a repeated block can never win: identical projections at a higher index
+        const int blk = entry_block(e);
+        const int rows = entry_rows(e);
+        if (!entry_repeat(e)) {             // a repeated block can never win: identical projections at a higher index
             const double* cv;
             const int* cr;
             int nparts = row_parts;
@@ -512,12 +520,13 @@ __global__ __launch_bounds__(256) void mp_finish_kernel(const Workspace ws, cons
         } else {
             coeff = qstep * (double)q;                        // residual update itself: mp_update_kernel (coalesced)
             if (best_idx < dict.num_base) {                   // unlock DetailBasis[choice]; duplicates are appended again
-                unsigned e = (unsigned)best_idx;
+                const int new_rows = dict.block_rows[best_idx];
+                unsigned e = (unsigned)best_idx | ((unsigned)new_rows << 9);
                 for (int i = 0; i < nb; ++i)
-                    if ((ws.blk_list[(long long)tc * kMaxDeviceK + i] & 0x7FFFu) == (unsigned)best_idx) e |= 0x8000u;
+                    if (entry_block(ws.blk_list[(long long)tc * kMaxDeviceK + i]) == best_idx) e |= 0x8000u;
                 ws.blk_list[(long long)tc * kMaxDeviceK + nb] = (uint16_t)e;
                 ws.nblk[tc] = nb + 1;
-                ws.extra_rows[tc] = extra + dict.block_rows[best_idx];
+                ws.extra_rows[tc] = extra + new_rows;
                 unlocked = true;
             }
             if (step + 1 == K) { done = true; count = K; }
@@ -555,8 +564,8 @@ __global__ __launch_bounds__(256) void mp_finish_kernel(const Workspace ws, cons
         const int nb2 = nb + (unlocked ? 1 : 0);
         for (int i = 0; i < nb2; ++i) {
             const unsigned e = ws.blk_list[(long long)tc * kMaxDeviceK + i];
-            if (e == 0 || (e & 0x8000u)) continue;
-            atomicAdd(&s_cnt[e], 1u);
+            if (!entry_is_item(e)) continue;
+            atomicAdd(&s_cnt[entry_block(e)], 1u);
         }
     }
     }
