@@ -58,6 +58,8 @@ __device__ __forceinline__ void load16(double (&g)[16], cptr_t p) {
 __global__ __launch_bounds__(64) void sweep_pipe(const double* __restrict__ base_g, int natoms, int wrap, double* outv,
                                                  unsigned long long* cycles, int desync)
 {
+    const int mode = desync >> 4;     // 0 normal, 1 no argmax (sum only), 2 fused multiply-add (NOT the reference arithmetic)
+    desync &= 15;
     double r[64];
 #pragma unroll
     for (int j = 0; j < 64; j++) r[j] = (double)((threadIdx.x * 7 + j * 3) % 31) - 15.0;
@@ -77,7 +79,8 @@ __global__ __launch_bounds__(64) void sweep_pipe(const double* __restrict__ base
         MAC_GROUP(gb, ga, 16, row + 32)
         MAC_GROUP(ga, gb, 32, row + 48)
         MAC_GROUP(gb, ga, 48, nxt)
-        if (__builtin_fabs(tot) > __builtin_fabs(best)) best = tot;
+        if (mode == 1) best += tot;
+        else if (__builtin_fabs(tot) > __builtin_fabs(best)) best = tot;
     }
     unsigned long long t1 = __builtin_readcyclecounter();
     const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
@@ -134,7 +137,7 @@ int main()
     const int natoms = 5100;
     for (int wrap : {510, 16}) {
         for (int waves : {2048, 3072}) run_pipe(d_base, natoms, wrap, waves, d_out, d_cyc);
-        for (int waves : {2048, 3072}) run_pipe(d_base, natoms, wrap, waves, d_out, d_cyc, 1);
+        for (int waves : {3072}) run_pipe(d_base, natoms, wrap, waves, d_out, d_cyc, 16);
 
     }
     return 0;
