@@ -63,7 +63,7 @@ def verify_scalar_sweeps(lib=LIB):
             f.write(data[st:])
         out = subprocess.run([objdump, "-d", tmp], capture_output=True, text=True).stdout
         os.remove(tmp)
-        for name in ("mp_base_kernel", "mp_detail_kernel"):
+        for name in ("mp_base_kernel", "mp_detail_kernel"):  # the exact sweeps (the filter kernel has no scalar-fed loop)
             m = re.search(name + r"[^\n]*>:(.*?)s_endpgm", out, re.S)
             if not m:
                 continue

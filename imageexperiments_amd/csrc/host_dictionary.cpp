@@ -506,18 +506,18 @@ std::vector<double> base_padded(const Dictionary& d, int pad_rows, int* padded_r
     return out;
 }
 
-std::vector<double> detail_transposed(const Dictionary& d) {
-    const int n = d.n;
-    const size_t block_elems = static_cast<size_t>(n / 2) * kBlockPad * 2;
-    std::vector<double> out(3 * static_cast<size_t>(d.num_base) * block_elems, 0.0);
-    for (int ch = 0; ch < 3; ++ch)
-        for (int b = 0; b < d.num_base; ++b) {
-            double* blk = out.data() + (static_cast<size_t>(ch) * d.num_base + b) * block_elems;
-            const double* src = d.detail[ch].data() + static_cast<size_t>(d.block_row_off[b]) * n;
-            for (int row = 0; row < d.block_rows[b]; ++row)
-                for (int j = 0; j < n; ++j)
-                    blk[(static_cast<size_t>(j / 2) * kBlockPad + row) * 2 + (j & 1)] = src[static_cast<size_t>(row) * n + j];
-        }
+std::vector<float> filter_tiles(const double* rows, int nrows, int tiles) {
+    std::vector<float> out(static_cast<size_t>(tiles) * kFilterTileFloats, 0.0f);
+    for (int tile = 0; tile < tiles; ++tile)
+        for (int kq = 0; kq < 8; ++kq)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 4; ++e) {
+                    const int row = tile * 32 + (lane & 31);
+                    const int k = 2 * (4 * kq + e) + (lane >> 5);
+                    if (row < nrows)
+                        out[((static_cast<size_t>(tile) * 8 + kq) * 64 + lane) * 4 + e] =
+                            static_cast<float>(rows[static_cast<size_t>(row) * kTileN + k]);
+                }
     return out;
 }
 

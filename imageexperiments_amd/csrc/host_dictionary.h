@@ -19,7 +19,6 @@ namespace mpc {
 
 constexpr int kMaxK = 32;
 constexpr int kTileN = 64;        // 8x8 tiles: the only block size the device path implements
-constexpr int kBlockPad = 64;     // detail blocks are padded to 64 rows in the transposed layout
 
 struct LineCut { int ax, ay, bx, by; };
 
@@ -56,9 +55,11 @@ void quantisation_tables(int K, int block_size, double bpp, double* quant);
 // Select starts from bestCoeff = 0 with a strict '>', MatchingPursuit.cpp:9-19).
 std::vector<double> base_padded(const Dictionary& d, int pad_rows, int* padded_rows);
 
-// Transposed detail blocks for the wave-per-tile sweep: for channel ch, block b:
-//   out[((ch*num_base + b) * (n/2) + jj) * 64*2 + row*2 + e] = detail[ch][off[b]+row][2*jj+e]
-// rows >= block_rows[b] are zero. 32 KiB per block.
-std::vector<double> detail_transposed(const Dictionary& d);
+// Single-precision copy of `nrows` dictionary rows (row-major doubles, n = 64) for the device's filter pass,
+// padded with zero rows to `tiles` tiles of 32 rows and laid out in the operand order of v_mfma_f32_32x32x2_f32:
+//   out[((tile*8 + kq)*64 + lane)*4 + e] = (float) rows[tile*32 + (lane & 31)][2*(4*kq + e) + (lane >> 5)]
+// so that one 16-byte load per lane feeds four consecutive MFMAs.  8 KiB per tile.
+std::vector<float> filter_tiles(const double* rows, int nrows, int tiles);
+constexpr int kFilterTileFloats = 2048;
 
 }  // namespace mpc

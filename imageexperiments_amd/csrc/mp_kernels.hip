@@ -269,6 +269,210 @@ __global__ __launch_bounds__(64, 3) void mp_base_kernel(const Workspace ws, cons
     }
 }
 
+// --------------------------------------------------------------------------------------------------
+// filtered base sweep.  The argmax of Select() only needs the exact projection of the rows that can be the
+// maximum.  So: (1) approximate ALL projections of a group of 32 tile-channels in single precision on the matrix
+// cores, (2) keep, per tile-channel, the rows whose approximation is within 2E of the largest one, (3) evaluate
+// only those in the reference's arithmetic (sequential double dot product, mathmatrix.cpp:436-444) and pick the
+// first strict maximum among them in row order.  The result is bit-identical to sweeping every row:
+//   * v_mfma_f32_32x32x2_f32 is an f32 fma chain in k order, so with u = 2^-24 its value differs from the real
+//     dot product by at most ((1+u)^66 - 1) * sum|r_j b_j| <= 66.01 u |r|_2 |b|_2 (operand roundings included),
+//     plus < 2^-142 where products fall into the f32 subnormal range; the reference's double value differs from
+//     the real one by < 2^-46 of that.  Rows have |b|_2 <= 1 + 2^-50.  E = 2^-17 |r|_2 + 2^-140 (= 128 u |r|_2 ...)
+//     leaves a factor ~1.9 over all of it.
+//   * let j* be the row Select() returns (lowest index with maximal exact |p|) and j~ the approximate maximum:
+//     approx|p_j*| >= |p_j*| - E >= |p_j~| - E >= approx|p_j~| - 2E, so j* is kept -- as is every row tying with it.
+//   * overflow / NaN anywhere makes the comparison `approx < threshold` false: the row is kept and evaluated.
+// The 63 rows of DetailBasis[0] (unlocked by the DC atom for nearly every tile-channel) ride along as two more
+// tiles with their own threshold and their own result slot.
+// Block = 128 threads = 2 waves, 32 tile-channels of one channel's active list; LDS holds the 32 x 576
+// approximations (72 KiB -> two blocks per CU, so one block's scan overlaps the other's MFMAs).
+// --------------------------------------------------------------------------------------------------
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kFilterGroup = 32;                                          // tile-channels per block
+constexpr int kFilterRows = 32 * (kBaseFilterTiles + kBlockFilterTiles);  // 576
+constexpr float kFilterSlack = 0x1p-17f;
+constexpr float kFilterAbs = 0x1p-140f;
+
+// the reference's dot product of one dictionary row with the residual held in registers
+__device__ __forceinline__ double dot_exact(const double* row, const double (&r)[N])
+{
+    const double2* src = (const double2*)row;
+    double tot = 0.0;
+#pragma unroll
+    for (int jj = 0; jj < N / 2; ++jj) {
+        const double2 v = src[jj];
+        tot += v.x * r[2 * jj];
+        tot += v.y * r[2 * jj + 1];
+    }
+    return tot;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(128) void mp_filter_kernel(const Workspace ws, const DictDevice dict, int cur, int with_detail0)
+{
+    __shared__ float s_p[kFilterRows * kFilterGroup];        // approximate projections [row][slot]
+    __shared__ float s_max[2][4][kFilterGroup];              // [base | block 0][quarter][slot]
+    __shared__ float s_norm[kFilterGroup];
+    __shared__ double s_val[2][4][kFilterGroup];
+    __shared__ int s_idx[2][4][kFilterGroup];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (blockIdx.x == 0 && t < 3) ws.counters[(cur ^ 1) * 3 + t] = 0;      // next step's active counts
+    const int n0 = (int)scalar_counter(ws.counters, cur * 3 + 0), n1 = (int)scalar_counter(ws.counters, cur * 3 + 1),
+              n2 = (int)scalar_counter(ws.counters, cur * 3 + 2);
+    const int g0 = (n0 + kFilterGroup - 1) / kFilterGroup, g1 = (n1 + kFilterGroup - 1) / kFilterGroup,
+              g2 = (n2 + kFilterGroup - 1) / kFilterGroup;
+    const int ntiles = kBaseFilterTiles + (with_detail0 ? kBlockFilterTiles : 0);
+    const int rows0 = dict.block_rows[0];
+    for (int u = blockIdx.x; u < g0 + g1 + g2; u += gridDim.x) {
+        const int ch = u < g0 ? 0 : (u < g0 + g1 ? 1 : 2);
+        const int group = u - (ch == 0 ? 0 : (ch == 1 ? g0 : g0 + g1));
+        const int n_act = ch == 0 ? n0 : (ch == 1 ? n1 : n2);
+        const int* act = ws.act[cur][ch];
+
+        // ---- (1) approximate projections: B operand = the 32 residuals (lane: slot l&31, k parity l>>5),
+        //          A operand = dictionary tiles in MFMA order; wave w takes tiles w, w+2, ...
+        {
+            const int pos = group * kFilterGroup + (lane & 31);
+            const int tc = act[pos < n_act ? pos : group * kFilterGroup];
+            const double2* src = (const double2*)(ws.r + (long long)tc * N);
+            const bool odd = (lane >> 5) != 0;
+            float rb[32];
+            double ss = 0.0;
+#pragma unroll
+            for (int kk = 0; kk < 32; ++kk) {
+                const double2 v = src[kk];
+                ss += v.x * v.x;
+                ss += v.y * v.y;
+                rb[kk] = (float)(odd ? v.y : v.x);
+            }
+            if (wave == 0 && lane < 32) s_norm[lane] = (float)__builtin_sqrt(ss);     // rounds to nearest: within the slack
+            const float* tiles0 = dict.detail_f32 + (long long)ch * dict.num_base * kBlockFilterTiles * 2048;
+            for (int tile = wave; tile < ntiles; tile += 2) {
+                const float4* a = (const float4*)(tile < kBaseFilterTiles ? dict.base_f32 + tile * 2048
+                                                                          : tiles0 + (tile - kBaseFilterTiles) * 2048);
+                float4 av[8];
+#pragma unroll
+                for (int kq = 0; kq < 8; ++kq) av[kq] = a[kq * 64 + lane];
+                f32x16 acc;
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
+#pragma unroll
+                for (int kq = 0; kq < 8; ++kq) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kq].x, rb[4 * kq + 0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kq].y, rb[4 * kq + 1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kq].z, rb[4 * kq + 2], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kq].w, rb[4 * kq + 3], acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int row = tile * 32 + (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);
+                    s_p[row * kFilterGroup + (lane & 31)] = acc[v];
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- (2) per tile-channel: largest approximation.  Thread = (slot, quarter of the rows).
+        const int slot = t & 31, q = t >> 5;
+        const int pos = group * kFilterGroup + slot;
+        const bool valid = pos < n_act;
+        const int tc = act[valid ? pos : group * kFilterGroup];
+        bool has0 = false;
+        if (with_detail0 && valid) {
+            const int nb = ws.nblk[tc];
+            for (int i = 0; i < nb; ++i)
+                if (entry_is_first_block0(ws.blk_list[(long long)tc * kMaxDeviceK + i])) has0 = true;
+        }
+        const int a_lo = q * 128, d_lo = 32 * kBaseFilterTiles + q * 16;
+        {
+            float mb = 0.0f, md = 0.0f;
+            for (int a = a_lo; a < a_lo + 128; ++a) mb = fmaxf(mb, fabsf(s_p[a * kFilterGroup + slot]));
+            if (with_detail0)
+                for (int a = d_lo; a < d_lo + 16; ++a) md = fmaxf(md, fabsf(s_p[a * kFilterGroup + slot]));
+            s_max[0][q][slot] = mb;
+            s_max[1][q][slot] = md;
+        }
+        __syncthreads();
+        const float window = 2.0f * (kFilterSlack * s_norm[slot] + kFilterAbs);
+        const float thr_b = fmaxf(fmaxf(s_max[0][0][slot], s_max[0][1][slot]), fmaxf(s_max[0][2][slot], s_max[0][3][slot])) - window;
+        const float thr_d = fmaxf(fmaxf(s_max[1][0][slot], s_max[1][1][slot]), fmaxf(s_max[1][2][slot], s_max[1][3][slot])) - window;
+
+        // ---- (3) the rows that can be the maximum, in ascending order, in the reference's arithmetic
+        int c0 = -1, c1 = -1, c2 = -1, c3 = -1, cnt = 0;            // first four; rows of block 0 are coded 512 + row
+        if (valid) {
+            const int a_hi = (a_lo + 128 < dict.num_base) ? a_lo + 128 : dict.num_base;
+            for (int a = a_lo; a < a_hi; ++a)
+                if (!(fabsf(s_p[a * kFilterGroup + slot]) < thr_b)) {
+                    if (cnt == 0) c0 = a; else if (cnt == 1) c1 = a; else if (cnt == 2) c2 = a; else if (cnt == 3) c3 = a;
+                    ++cnt;
+                }
+        }
+        if (has0) {
+            const int hi = (q * 16 + 16 < rows0) ? q * 16 + 16 : rows0;
+            for (int a = q * 16; a < hi; ++a)
+                if (!(fabsf(s_p[(32 * kBaseFilterTiles + a) * kFilterGroup + slot]) < thr_d)) {
+                    const int code = 512 + a;
+                    if (cnt == 0) c0 = code; else if (cnt == 1) c1 = code; else if (cnt == 2) c2 = code; else if (cnt == 3) c3 = code;
+                    ++cnt;
+                }
+        }
+        double bv = 0.0, dv = 0.0;
+        int bi = -1, di = -1;
+        if (cnt > 0) {
+            double r[N];
+            load_residual(r, ws.r + (long long)tc * N);
+            const double* block0 = dict.detail + (long long)ch * dict.detail_rows * N;
+            if (cnt <= 4) {
+                for (int i = 0; i < cnt; ++i) {
+                    const int code = i == 0 ? c0 : (i == 1 ? c1 : (i == 2 ? c2 : c3));
+                    const double p = dot_exact(code < 512 ? dict.base + (long long)code * N : block0 + (long long)(code - 512) * N, r);
+                    if (code < 512) { if (__builtin_fabs(p) > __builtin_fabs(bv)) { bv = p; bi = code; } }
+                    else if (__builtin_fabs(p) > __builtin_fabs(dv)) { dv = p; di = code - 512; }
+                }
+            } else {
+                // more than four (a flat or degenerate residual): walk the ranges again, evaluating as we go
+                if (valid) {
+                    const int a_hi = (a_lo + 128 < dict.num_base) ? a_lo + 128 : dict.num_base;
+                    for (int a = a_lo; a < a_hi; ++a)
+                        if (!(fabsf(s_p[a * kFilterGroup + slot]) < thr_b)) {
+                            const double p = dot_exact(dict.base + (long long)a * N, r);
+                            if (__builtin_fabs(p) > __builtin_fabs(bv)) { bv = p; bi = a; }
+                        }
+                }
+                if (has0) {
+                    const int hi = (q * 16 + 16 < rows0) ? q * 16 + 16 : rows0;
+                    for (int a = q * 16; a < hi; ++a)
+                        if (!(fabsf(s_p[(32 * kBaseFilterTiles + a) * kFilterGroup + slot]) < thr_d)) {
+                            const double p = dot_exact(block0 + (long long)a * N, r);
+                            if (__builtin_fabs(p) > __builtin_fabs(dv)) { dv = p; di = a; }
+                        }
+                }
+            }
+        }
+        s_val[0][q][slot] = bv; s_idx[0][q][slot] = bi;
+        s_val[1][q][slot] = dv; s_idx[1][q][slot] = di;
+        __syncthreads();
+        if (q == 0 && valid) {
+            for (int k = 1; k < 4; ++k) {                              // quarters in row order, strict '>'
+                if (__builtin_fabs(s_val[0][k][slot]) > __builtin_fabs(bv)) { bv = s_val[0][k][slot]; bi = s_idx[0][k][slot]; }
+                if (__builtin_fabs(s_val[1][k][slot]) > __builtin_fabs(dv)) { dv = s_val[1][k][slot]; di = s_idx[1][k][slot]; }
+            }
+            ws.part_val[(long long)tc * kMaxParts] = bv;
+            ws.part_idx[(long long)tc * kMaxParts] = bi;
+            if (has0) {
+                ws.cand0_val[tc] = dv;
+                ws.cand0_row[tc] = di;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // Row range `part` of `row_parts` of a block with `rows` rows: [lo, hi)
 __device__ __forceinline__ void row_range(int rows, int row_parts, int part, int& lo, int& hi)
 {
@@ -826,6 +1030,7 @@ int enqueue_pursuit(const DictDevice& dict, const Workspace& ws, const FrameInpu
     hipEvent_t ev_fork = static_cast<hipEvent_t>(fork_event_), ev_join = static_cast<hipEvent_t>(join_event_);
     const bool forked = side != nullptr && ev_fork != nullptr && ev_join != nullptr;
     if (n < 1 || n > ws.cap) return (int)hipErrorInvalidValue;
+    const bool filtered = parts < 1;          // base rows (+ block 0) through the MFMA filter instead of the full sweep
     if (parts < 1) parts = 1;
     if (parts > kMaxParts) parts = kMaxParts;
     if (row_parts < 1) row_parts = 1;
@@ -857,8 +1062,12 @@ int enqueue_pursuit(const DictDevice& dict, const Workspace& ws, const FrameInpu
                                    dict, row_parts, (int)slots, ws.cand_val);
         }
         if (base_events) (void)hipEventRecord(static_cast<hipEvent_t>(base_events[2 * step]), s);
-        hipLaunchKernelGGL(mp_base_kernel, dim3(clampu(max_groups * (unsigned)(parts + 1), slots)), dim3(64), 0, s, ws, dict,
-                           cur, parts, step > 0 ? 1 : 0, (int)slots);
+        if (filtered)
+            hipLaunchKernelGGL(mp_filter_kernel, dim3(clampu(lists * (unsigned)((per_list + 31) / 32), 512u)), dim3(128), 0, s, ws,
+                               dict, cur, step > 0 ? 1 : 0);
+        else
+            hipLaunchKernelGGL(mp_base_kernel, dim3(clampu(max_groups * (unsigned)(parts + 1), slots)), dim3(64), 0, s, ws, dict,
+                               cur, parts, step > 0 ? 1 : 0, (int)slots);
         if (base_events) (void)hipEventRecord(static_cast<hipEvent_t>(base_events[2 * step + 1]), s);
         if (step > 0) {
             if (forked) {

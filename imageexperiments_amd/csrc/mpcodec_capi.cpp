@@ -58,6 +58,8 @@ struct mpc_context {
     double* d_quant = nullptr;
     int32_t* d_rows = nullptr;
     int32_t* d_rowoff = nullptr;
+    float* d_base_f32 = nullptr;      // filter copies (mp_device.h)
+    float* d_detail_f32 = nullptr;
     int* d_flag = nullptr;            // decode: set when a record indexes outside its dictionary
     // The pursuit of a call is cut into sub-batches that run on `pipes` internal streams, each with its own
     // workspace: the latency-bound bookkeeping kernels of one sub-batch (finish, update, bucket, fill) overlap
@@ -107,6 +109,8 @@ mpc::DictDevice dict_device(const mpc_context* c) {
     d.detail_rows = c->dict.total_detail_rows();
     d.block_rows = c->d_rows;
     d.block_row_off = c->d_rowoff;
+    d.base_f32 = c->d_base_f32;
+    d.detail_f32 = c->d_detail_f32;
     return d;
 }
 
@@ -193,7 +197,7 @@ mpc_status run_pursuit(mpc_context* c, const mpc::FrameInput& in, const mpc::Out
             c->timing_used = need;
         }
         const int err = mpc::enqueue_pursuit(dict, pipe.ws, in, out, d_quant, c->K, begin, static_cast<int>(n),
-                                             env_int("MPC_BASE_PARTS", kBaseParts), env_int("MPC_ROW_PARTS", kRowParts),
+                                             env_int("MPC_FILTER", 1) ? 0 : env_int("MPC_BASE_PARTS", kBaseParts), env_int("MPC_ROW_PARTS", kRowParts),
                                              env_int("MPC_SWEEP_WAVES", c->max_waves), pipe.stream, events,
                                              env_int("MPC_SIDE", 0) ? pipe.side : nullptr, pipe.fork, pipe.join);
         if (err != 0) return fail(MPC_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(err)));
@@ -251,6 +255,21 @@ mpc_status mpc_context_create(int K, int block_size, double bpp, int device, mpc
         if (e == hipSuccess) e = upload(&c->d_quant, c->quant.data(), c->quant.size());
         if (e == hipSuccess) e = upload(&c->d_rows, c->dict.block_rows.data(), c->dict.block_rows.size());
         if (e == hipSuccess) e = upload(&c->d_rowoff, c->dict.block_row_off.data(), c->dict.block_row_off.size());
+        // single-precision copies for the filter pass: base rows as 16 tiles, every detail block as 2 tiles
+        {
+            const std::vector<float> base32 = mpc::filter_tiles(c->dict.base.data(), c->dict.num_base, mpc::kBaseFilterTiles);
+            std::vector<float> det32;
+            det32.reserve(3 * static_cast<size_t>(c->dict.num_base) * mpc::kBlockFilterTiles * mpc::kFilterTileFloats);
+            for (int ch = 0; ch < 3; ++ch)
+                for (int b = 0; b < c->dict.num_base; ++b) {
+                    const std::vector<float> t = mpc::filter_tiles(
+                        c->dict.detail[ch].data() + static_cast<size_t>(c->dict.block_row_off[b]) * mpc::kTileN,
+                        c->dict.block_rows[b], mpc::kBlockFilterTiles);
+                    det32.insert(det32.end(), t.begin(), t.end());
+                }
+            if (e == hipSuccess) e = upload(&c->d_base_f32, base32.data(), base32.size());
+            if (e == hipSuccess) e = upload(&c->d_detail_f32, det32.data(), det32.size());
+        }
 
         if (e != hipSuccess) {
             mpc_context_destroy(c);
@@ -272,6 +291,8 @@ void mpc_context_destroy(mpc_context* c) {
         (void)hipFree(c->d_quant);
         (void)hipFree(c->d_rows);
         (void)hipFree(c->d_rowoff);
+        (void)hipFree(c->d_base_f32);
+        (void)hipFree(c->d_detail_f32);
         (void)hipFree(c->d_flag);
         for (auto& p : c->pipes) {
             if (p.mem) (void)hipFree(p.mem);
