@@ -507,15 +507,27 @@ std::vector<double> base_padded(const Dictionary& d, int pad_rows, int* padded_r
 }
 
 std::vector<float> filter_tiles(const double* rows, int nrows, int tiles) {
+    std::vector<char> shadowed(static_cast<size_t>(nrows), 0);
+    for (int j = 1; j < nrows; ++j)
+        for (int i = 0; i < j && !shadowed[j]; ++i) {
+            bool same = true, negated = true;
+            for (int k = 0; k < kTileN && (same || negated); ++k) {
+                const double a = rows[static_cast<size_t>(i) * kTileN + k], b = rows[static_cast<size_t>(j) * kTileN + k];
+                if (std::memcmp(&a, &b, sizeof(double)) != 0) same = false;
+                const double nb = -b;
+                if (std::memcmp(&a, &nb, sizeof(double)) != 0) negated = false;
+            }
+            if (same || negated) shadowed[j] = 1;
+        }
     std::vector<float> out(static_cast<size_t>(tiles) * kFilterTileFloats, 0.0f);
     for (int tile = 0; tile < tiles; ++tile)
-        for (int kq = 0; kq < 8; ++kq)
+        for (int kq = 0; kq < 4; ++kq)
             for (int lane = 0; lane < 64; ++lane)
                 for (int e = 0; e < 4; ++e) {
-                    const int row = tile * 32 + (lane & 31);
-                    const int k = 2 * (4 * kq + e) + (lane >> 5);
-                    if (row < nrows)
-                        out[((static_cast<size_t>(tile) * 8 + kq) * 64 + lane) * 4 + e] =
+                    const int row = tile * 16 + (lane & 15);
+                    const int k = 4 * (4 * kq + e) + (lane >> 4);
+                    if (row < nrows && !shadowed[row])
+                        out[((static_cast<size_t>(tile) * 4 + kq) * 64 + lane) * 4 + e] =
                             static_cast<float>(rows[static_cast<size_t>(row) * kTileN + k]);
                 }
     return out;

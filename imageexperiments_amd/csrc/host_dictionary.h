@@ -56,10 +56,12 @@ void quantisation_tables(int K, int block_size, double bpp, double* quant);
 std::vector<double> base_padded(const Dictionary& d, int pad_rows, int* padded_rows);
 
 // Single-precision copy of `nrows` dictionary rows (row-major doubles, n = 64) for the device's filter pass,
-// padded with zero rows to `tiles` tiles of 32 rows and laid out in the operand order of v_mfma_f32_32x32x2_f32:
-//   out[((tile*8 + kq)*64 + lane)*4 + e] = (float) rows[tile*32 + (lane & 31)][2*(4*kq + e) + (lane >> 5)]
-// so that one 16-byte load per lane feeds four consecutive MFMAs.  8 KiB per tile.
+// padded with zero rows to `tiles` tiles of 16 rows and laid out in the operand order of v_mfma_f32_16x16x4_f32:
+//   out[((tile*4 + kq)*64 + lane)*4 + e] = (float) rows[tile*16 + (lane & 15)][4*(4*kq + e) + (lane >> 4)]
+// so that one 16-byte load per lane feeds four consecutive MFMAs.  4 KiB per tile.
+// A row that is bit-for-bit +-(an earlier row) is left zero: its projection ties with the earlier row's exactly
+// (IEEE negation commutes with every rounding of the dot product), so Select()'s strict '>' never returns it.
 std::vector<float> filter_tiles(const double* rows, int nrows, int tiles);
-constexpr int kFilterTileFloats = 2048;
+constexpr int kFilterTileFloats = 1024;
 
 }  // namespace mpc

@@ -270,57 +270,109 @@ __global__ __launch_bounds__(64, 3) void mp_base_kernel(const Workspace ws, cons
 }
 
 // --------------------------------------------------------------------------------------------------
-// filtered base sweep.  The argmax of Select() only needs the exact projection of the rows that can be the
-// maximum.  So: (1) approximate ALL projections of a group of 32 tile-channels in single precision on the matrix
+// filtered sweeps.  The argmax of Select() only needs the exact projection of the rows that can be the
+// maximum.  So: (1) approximate ALL projections of a group of 16 tile-channels in single precision on the matrix
 // cores, (2) keep, per tile-channel, the rows whose approximation is within 2E of the largest one, (3) evaluate
 // only those in the reference's arithmetic (sequential double dot product, mathmatrix.cpp:436-444) and pick the
 // first strict maximum among them in row order.  The result is bit-identical to sweeping every row:
-//   * v_mfma_f32_32x32x2_f32 is an f32 fma chain in k order, so with u = 2^-24 its value differs from the real
+//   * v_mfma_f32_16x16x4_f32 is an f32 fma chain in k order, so with u = 2^-24 its value differs from the real
 //     dot product by at most ((1+u)^66 - 1) * sum|r_j b_j| <= 66.01 u |r|_2 |b|_2 (operand roundings included),
 //     plus < 2^-142 where products fall into the f32 subnormal range; the reference's double value differs from
-//     the real one by < 2^-46 of that.  Rows have |b|_2 <= 1 + 2^-50.  E = 2^-17 |r|_2 + 2^-140 (= 128 u |r|_2 ...)
-//     leaves a factor ~1.9 over all of it.
+//     the real one by < 2^-46 of that.  Rows have |b|_2 <= 1 + 2^-50.  E = 2^-17 |r~|_2 + 2^-140 (128 u |r~|_2, r~ the
+//     f32-rounded residual) leaves a factor ~1.9 over all of it.
 //   * let j* be the row Select() returns (lowest index with maximal exact |p|) and j~ the approximate maximum:
 //     approx|p_j*| >= |p_j*| - E >= |p_j~| - E >= approx|p_j~| - 2E, so j* is kept -- as is every row tying with it.
 //   * overflow / NaN anywhere makes the comparison `approx < threshold` false: the row is kept and evaluated.
-// The 63 rows of DetailBasis[0] (unlocked by the DC atom for nearly every tile-channel) ride along as two more
-// tiles with their own threshold and their own result slot.
-// Block = 128 threads = 2 waves, 32 tile-channels of one channel's active list; LDS holds the 32 x 576
-// approximations (72 KiB -> two blocks per CU, so one block's scan overlaps the other's MFMAs).
+//   * rows that are +-copies of an earlier row (base row 509 = -row 0) are zero in the f32 copy: they tie with the
+//     earlier row exactly and can never be returned (host_dictionary.cpp: filter_tiles).
 // --------------------------------------------------------------------------------------------------
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kFilterGroup = 32;                                          // tile-channels per block
-constexpr int kFilterRows = 32 * (kBaseFilterTiles + kBlockFilterTiles);  // 576
+constexpr int kFilterGroup = 16;                                          // tile-channels per MFMA column block
+constexpr int kFilterRows = 16 * (kBaseFilterTiles + kBlockFilterTiles);  // 576 = 512 base + 64 of block 0
+constexpr int kStageStride = N + 1;                                       // doubles per staged residual (+1: bank spread)
 constexpr float kFilterSlack = 0x1p-17f;
 constexpr float kFilterAbs = 0x1p-140f;
 
-// the reference's dot product of one dictionary row with the residual held in registers
-__device__ __forceinline__ double dot_exact(const double* row, const double (&r)[N])
+// the reference's dot product of one dictionary row with a residual staged in LDS
+__device__ __forceinline__ double dot_exact(const double* row, const double* r_lds)
 {
     const double2* src = (const double2*)row;
     double tot = 0.0;
+#pragma unroll 1
+    for (int b = 0; b < N / 2; b += 8) {                     // 8 row loads in flight: bounded register use
+        double2 v[8];
 #pragma unroll
-    for (int jj = 0; jj < N / 2; ++jj) {
-        const double2 v = src[jj];
-        tot += v.x * r[2 * jj];
-        tot += v.y * r[2 * jj + 1];
+        for (int jj = 0; jj < 8; ++jj) v[jj] = src[b + jj];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            tot += v[jj].x * r_lds[2 * (b + jj)];
+            tot += v[jj].y * r_lds[2 * (b + jj) + 1];
+        }
     }
     return tot;
 }
 
+// B operand of the 16x16x4 MFMAs for 16 staged residuals: lane (slot = l & 15, kg = l >> 4) holds r~[slot][4kk + kg];
+// also returns |r~[slot]|^2 (summed over the four kg lanes)
+__device__ __forceinline__ double load_b_operand(float (&rb)[16], const double* stage, int lane)
+{
+    const double* src = stage + (lane & 15) * kStageStride + (lane >> 4);
+    double ss = 0.0;
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+        rb[kk] = (float)src[4 * kk];
+        ss += (double)rb[kk] * (double)rb[kk];
+    }
+    ss += __shfl_xor(ss, 16);
+    ss += __shfl_xor(ss, 32);
+    return ss;
+}
+
+// 16 rows x 16 residuals: one f32 tile of the filter copy against the B operand
+__device__ __forceinline__ f32x4 mfma_tile(const float4* tile, const float (&rb)[16], int lane)
+{
+    float4 av[4];
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) av[kq] = tile[kq * 64 + lane];
+    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kq].x, rb[4 * kq + 0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kq].y, rb[4 * kq + 1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kq].z, rb[4 * kq + 2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kq].w, rb[4 * kq + 3], acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+// keep the better of two (value, row) results of disjoint row sets: larger |value|, on a tie the lower row
+__device__ __forceinline__ void keep_better(double& v, int& i, double ov, int oi)
+{
+    if (oi >= 0 && (i < 0 || __builtin_fabs(ov) > __builtin_fabs(v) || (__builtin_fabs(ov) == __builtin_fabs(v) && oi < i))) {
+        v = ov;
+        i = oi;
+    }
+}
+
 }  // namespace
 
-__global__ __launch_bounds__(128) void mp_filter_kernel(const Workspace ws, const DictDevice dict, int cur, int with_detail0)
+// Base rows and (steps > 0) the 63 rows of DetailBasis[0], which the DC atom unlocks for nearly every tile-channel:
+// they ride along as four more tiles with their own threshold and their own result slot.
+// Block = 256 threads = 4 waves, 16 tile-channels of one channel's active list; 47 KiB of LDS, three blocks per CU.
+__global__ __launch_bounds__(256, 3) void mp_filter_kernel(const Workspace ws, const DictDevice dict, int cur, int with_detail0)
 {
     __shared__ float s_p[kFilterRows * kFilterGroup];        // approximate projections [row][slot]
-    __shared__ float s_max[2][4][kFilterGroup];              // [base | block 0][quarter][slot]
-    __shared__ float s_norm[kFilterGroup];
+    __shared__ double s_r[kFilterGroup * kStageStride];      // the 16 residuals
+    __shared__ float s_max[2][4][kFilterGroup];              // [base | block 0][wave][slot]
     __shared__ double s_val[2][4][kFilterGroup];
     __shared__ int s_idx[2][4][kFilterGroup];
+    __shared__ int s_tc[kFilterGroup];
+    __shared__ int s_flags[kFilterGroup];                    // bit 0: residual has a non-zero element; bit 1: block 0 unlocked
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int slot = lane & 15, sub = lane >> 4;
     if (blockIdx.x == 0 && t < 3) ws.counters[(cur ^ 1) * 3 + t] = 0;      // next step's active counts
     const int n0 = (int)scalar_counter(ws.counters, cur * 3 + 0), n1 = (int)scalar_counter(ws.counters, cur * 3 + 1),
               n2 = (int)scalar_counter(ws.counters, cur * 3 + 2);
@@ -334,137 +386,120 @@ __global__ __launch_bounds__(128) void mp_filter_kernel(const Workspace ws, cons
         const int n_act = ch == 0 ? n0 : (ch == 1 ? n1 : n2);
         const int* act = ws.act[cur][ch];
 
-        // ---- (1) approximate projections: B operand = the 32 residuals (lane: slot l&31, k parity l>>5),
-        //          A operand = dictionary tiles in MFMA order; wave w takes tiles w, w+2, ...
-        {
-            const int pos = group * kFilterGroup + (lane & 31);
-            const int tc = act[pos < n_act ? pos : group * kFilterGroup];
-            const double2* src = (const double2*)(ws.r + (long long)tc * N);
-            const bool odd = (lane >> 5) != 0;
-            float rb[32];
-            double ss = 0.0;
+        // ---- stage the 16 residuals: wave w brings rows 4w..4w+3, lane = pixel (one coalesced 512-byte read each)
 #pragma unroll
-            for (int kk = 0; kk < 32; ++kk) {
-                const double2 v = src[kk];
-                ss += v.x * v.x;
-                ss += v.y * v.y;
-                rb[kk] = (float)(odd ? v.y : v.x);
-            }
-            if (wave == 0 && lane < 32) s_norm[lane] = (float)__builtin_sqrt(ss);     // rounds to nearest: within the slack
-            const float* tiles0 = dict.detail_f32 + (long long)ch * dict.num_base * kBlockFilterTiles * 2048;
-            for (int tile = wave; tile < ntiles; tile += 2) {
-                const float4* a = (const float4*)(tile < kBaseFilterTiles ? dict.base_f32 + tile * 2048
-                                                                          : tiles0 + (tile - kBaseFilterTiles) * 2048);
-                float4 av[8];
-#pragma unroll
-                for (int kq = 0; kq < 8; ++kq) av[kq] = a[kq * 64 + lane];
-                f32x16 acc;
-#pragma unroll
-                for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
-#pragma unroll
-                for (int kq = 0; kq < 8; ++kq) {
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kq].x, rb[4 * kq + 0], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kq].y, rb[4 * kq + 1], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kq].z, rb[4 * kq + 2], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kq].w, rb[4 * kq + 3], acc, 0, 0, 0);
+        for (int i = 0; i < 4; ++i) {
+            const int sl = wave * 4 + i;
+            const int pos = group * kFilterGroup + sl;
+            const bool ok = pos < n_act;
+            const int tc = act[ok ? pos : group * kFilterGroup];
+            const double v = ws.r[(long long)tc * N + lane];
+            s_r[sl * kStageStride + lane] = v;
+            const bool nz = __ballot(v != 0.0) != 0;
+            if (lane == 0) {
+                bool has0 = false;
+                if (with_detail0 && ok) {
+                    const int nb = ws.nblk[tc];
+                    for (int k = 0; k < nb; ++k)
+                        if (entry_is_first_block0(ws.blk_list[(long long)tc * kMaxDeviceK + k])) has0 = true;
                 }
-#pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    const int row = tile * 32 + (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);
-                    s_p[row * kFilterGroup + (lane & 31)] = acc[v];
-                }
+                s_tc[sl] = ok ? tc : -1;
+                s_flags[sl] = (nz ? 1 : 0) | (has0 ? 2 : 0);
             }
         }
         __syncthreads();
 
-        // ---- (2) per tile-channel: largest approximation.  Thread = (slot, quarter of the rows).
-        const int slot = t & 31, q = t >> 5;
-        const int pos = group * kFilterGroup + slot;
-        const bool valid = pos < n_act;
-        const int tc = act[valid ? pos : group * kFilterGroup];
-        bool has0 = false;
-        if (with_detail0 && valid) {
-            const int nb = ws.nblk[tc];
-            for (int i = 0; i < nb; ++i)
-                if (entry_is_first_block0(ws.blk_list[(long long)tc * kMaxDeviceK + i])) has0 = true;
-        }
-        const int a_lo = q * 128, d_lo = 32 * kBaseFilterTiles + q * 16;
+        // ---- (1) approximate projections; wave w takes tiles w, w+4, ...
+        float window;
         {
-            float mb = 0.0f, md = 0.0f;
-            for (int a = a_lo; a < a_lo + 128; ++a) mb = fmaxf(mb, fabsf(s_p[a * kFilterGroup + slot]));
-            if (with_detail0)
-                for (int a = d_lo; a < d_lo + 16; ++a) md = fmaxf(md, fabsf(s_p[a * kFilterGroup + slot]));
-            s_max[0][q][slot] = mb;
-            s_max[1][q][slot] = md;
+            float rb[16];
+            const double ss = load_b_operand(rb, s_r, lane);
+            window = 2.0f * (kFilterSlack * (float)__builtin_sqrt(ss) + kFilterAbs);
+            const float* tiles0 = dict.detail_f32 + (long long)ch * dict.num_base * kBlockFilterTiles * 1024;
+            for (int tile = wave; tile < ntiles; tile += 4) {
+                const float4* a = (const float4*)(tile < kBaseFilterTiles ? dict.base_f32 + tile * 1024
+                                                                          : tiles0 + (tile - kBaseFilterTiles) * 1024);
+                const f32x4 acc = mfma_tile(a, rb, lane);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) s_p[(tile * 16 + sub * 4 + v) * kFilterGroup + slot] = acc[v];
+            }
         }
         __syncthreads();
-        const float window = 2.0f * (kFilterSlack * s_norm[slot] + kFilterAbs);
+
+        // ---- (2) largest approximation per tile-channel.  Wave w scans base rows [128w, 128w+128) and block-0 rows
+        //          [16w, 16w+16); lane (slot, sub) takes every fourth row (conflict-free LDS reads) and keeps them.
+        float pb[32], pd[4];
+        {
+            float mb = 0.0f, md = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                pb[i] = fabsf(s_p[(wave * 128 + 4 * i + sub) * kFilterGroup + slot]);
+                mb = fmaxf(mb, pb[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                pd[i] = with_detail0 ? fabsf(s_p[(16 * kBaseFilterTiles + wave * 16 + 4 * i + sub) * kFilterGroup + slot]) : 0.0f;
+                md = fmaxf(md, pd[i]);
+            }
+            mb = fmaxf(mb, __shfl_xor(mb, 16)); mb = fmaxf(mb, __shfl_xor(mb, 32));
+            md = fmaxf(md, __shfl_xor(md, 16)); md = fmaxf(md, __shfl_xor(md, 32));
+            if (sub == 0) { s_max[0][wave][slot] = mb; s_max[1][wave][slot] = md; }
+        }
+        __syncthreads();
         const float thr_b = fmaxf(fmaxf(s_max[0][0][slot], s_max[0][1][slot]), fmaxf(s_max[0][2][slot], s_max[0][3][slot])) - window;
         const float thr_d = fmaxf(fmaxf(s_max[1][0][slot], s_max[1][1][slot]), fmaxf(s_max[1][2][slot], s_max[1][3][slot])) - window;
 
-        // ---- (3) the rows that can be the maximum, in ascending order, in the reference's arithmetic
-        int c0 = -1, c1 = -1, c2 = -1, c3 = -1, cnt = 0;            // first four; rows of block 0 are coded 512 + row
-        if (valid) {
-            const int a_hi = (a_lo + 128 < dict.num_base) ? a_lo + 128 : dict.num_base;
-            for (int a = a_lo; a < a_hi; ++a)
-                if (!(fabsf(s_p[a * kFilterGroup + slot]) < thr_b)) {
-                    if (cnt == 0) c0 = a; else if (cnt == 1) c1 = a; else if (cnt == 2) c2 = a; else if (cnt == 3) c3 = a;
-                    ++cnt;
-                }
-        }
-        if (has0) {
-            const int hi = (q * 16 + 16 < rows0) ? q * 16 + 16 : rows0;
-            for (int a = q * 16; a < hi; ++a)
-                if (!(fabsf(s_p[(32 * kBaseFilterTiles + a) * kFilterGroup + slot]) < thr_d)) {
-                    const int code = 512 + a;
-                    if (cnt == 0) c0 = code; else if (cnt == 1) c1 = code; else if (cnt == 2) c2 = code; else if (cnt == 3) c3 = code;
-                    ++cnt;
-                }
+        // ---- (3) the rows that can be the maximum, ascending, in the reference's arithmetic
+        const int tc = s_tc[slot];
+        const int flags = s_flags[slot];
+        unsigned mask_b = 0, mask_d = 0;
+        if (tc >= 0 && (flags & 1)) {                       // an all-zero residual projects to 0 everywhere: index -1
+#pragma unroll
+            for (int i = 0; i < 32; ++i)
+                if (!(pb[i] < thr_b) && wave * 128 + 4 * i + sub < dict.num_base) mask_b |= 1u << i;
+            if (flags & 2) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (!(pd[i] < thr_d) && wave * 16 + 4 * i + sub < rows0) mask_d |= 1u << i;
+            }
         }
         double bv = 0.0, dv = 0.0;
         int bi = -1, di = -1;
-        if (cnt > 0) {
-            double r[N];
-            load_residual(r, ws.r + (long long)tc * N);
-            const double* block0 = dict.detail + (long long)ch * dict.detail_rows * N;
-            if (cnt <= 4) {
-                for (int i = 0; i < cnt; ++i) {
-                    const int code = i == 0 ? c0 : (i == 1 ? c1 : (i == 2 ? c2 : c3));
-                    const double p = dot_exact(code < 512 ? dict.base + (long long)code * N : block0 + (long long)(code - 512) * N, r);
-                    if (code < 512) { if (__builtin_fabs(p) > __builtin_fabs(bv)) { bv = p; bi = code; } }
-                    else if (__builtin_fabs(p) > __builtin_fabs(dv)) { dv = p; di = code - 512; }
-                }
-            } else {
-                // more than four (a flat or degenerate residual): walk the ranges again, evaluating as we go
-                if (valid) {
-                    const int a_hi = (a_lo + 128 < dict.num_base) ? a_lo + 128 : dict.num_base;
-                    for (int a = a_lo; a < a_hi; ++a)
-                        if (!(fabsf(s_p[a * kFilterGroup + slot]) < thr_b)) {
-                            const double p = dot_exact(dict.base + (long long)a * N, r);
-                            if (__builtin_fabs(p) > __builtin_fabs(bv)) { bv = p; bi = a; }
-                        }
-                }
-                if (has0) {
-                    const int hi = (q * 16 + 16 < rows0) ? q * 16 + 16 : rows0;
-                    for (int a = q * 16; a < hi; ++a)
-                        if (!(fabsf(s_p[(32 * kBaseFilterTiles + a) * kFilterGroup + slot]) < thr_d)) {
-                            const double p = dot_exact(block0 + (long long)a * N, r);
-                            if (__builtin_fabs(p) > __builtin_fabs(dv)) { dv = p; di = a; }
-                        }
-                }
-            }
+        const double* r_lds = s_r + slot * kStageStride;
+        while (mask_b) {
+            const int i = __builtin_ctz(mask_b);
+            mask_b &= mask_b - 1;
+            const int a = wave * 128 + 4 * i + sub;
+            const double p = dot_exact(dict.base + (long long)a * N, r_lds);
+            if (__builtin_fabs(p) > __builtin_fabs(bv)) { bv = p; bi = a; }
         }
-        s_val[0][q][slot] = bv; s_idx[0][q][slot] = bi;
-        s_val[1][q][slot] = dv; s_idx[1][q][slot] = di;
+        while (mask_d) {
+            const int i = __builtin_ctz(mask_d);
+            mask_d &= mask_d - 1;
+            const int a = wave * 16 + 4 * i + sub;
+            const double p = dot_exact(dict.detail + ((long long)ch * dict.detail_rows + a) * N, r_lds);
+            if (__builtin_fabs(p) > __builtin_fabs(dv)) { dv = p; di = a; }
+        }
+        // the four lanes of a slot hold interleaved rows: combine by (|value|, lower row)
+        keep_better(bv, bi, __shfl_xor(bv, 16), __shfl_xor(bi, 16));
+        keep_better(bv, bi, __shfl_xor(bv, 32), __shfl_xor(bi, 32));
+        keep_better(dv, di, __shfl_xor(dv, 16), __shfl_xor(di, 16));
+        keep_better(dv, di, __shfl_xor(dv, 32), __shfl_xor(di, 32));
+        if (sub == 0) {
+            s_val[0][wave][slot] = bv; s_idx[0][wave][slot] = bi;
+            s_val[1][wave][slot] = dv; s_idx[1][wave][slot] = di;
+        }
         __syncthreads();
-        if (q == 0 && valid) {
-            for (int k = 1; k < 4; ++k) {                              // quarters in row order, strict '>'
-                if (__builtin_fabs(s_val[0][k][slot]) > __builtin_fabs(bv)) { bv = s_val[0][k][slot]; bi = s_idx[0][k][slot]; }
-                if (__builtin_fabs(s_val[1][k][slot]) > __builtin_fabs(dv)) { dv = s_val[1][k][slot]; di = s_idx[1][k][slot]; }
+        if (t < kFilterGroup && tc >= 0) {                  // t == slot; waves hold ascending row ranges
+            bv = s_val[0][0][t]; bi = s_idx[0][0][t];
+            dv = s_val[1][0][t]; di = s_idx[1][0][t];
+            for (int k = 1; k < 4; ++k) {
+                keep_better(bv, bi, s_val[0][k][t], s_idx[0][k][t]);
+                keep_better(dv, di, s_val[1][k][t], s_idx[1][k][t]);
             }
             ws.part_val[(long long)tc * kMaxParts] = bv;
             ws.part_idx[(long long)tc * kMaxParts] = bi;
-            if (has0) {
+            if (flags & 2) {
                 ws.cand0_val[tc] = dv;
                 ws.cand0_row[tc] = di;
             }
@@ -535,6 +570,82 @@ __global__ __launch_bounds__(64, 3) void mp_detail_kernel(const Workspace ws, co
         }
     }
     if (keep == 123456.789) touch_sink[lane] = keep;          // never true: keeps the touch loads alive
+}
+
+// filtered detail sweep: the same filter for the bucketed detail blocks.  One wave per 16 items of a chunk
+// (<= 64 items of one (channel, block) bucket): 64 x 16 approximations (4 tiles, 64 MFMAs), then lane (slot, sub)
+// scans every fourth row of its item and the survivors are evaluated exactly.  12 KiB of LDS per wave.
+__global__ __launch_bounds__(64, 4) void mp_detail_filter_kernel(const Workspace ws, const DictDevice dict)
+{
+    __shared__ float s_p[64 * kFilterGroup];                 // approximate projections [row][slot]
+    __shared__ double s_r[kFilterGroup * kStageStride];
+    const int lane = threadIdx.x;
+    const int slot = lane & 15, sub = lane >> 4;
+    const unsigned n_units = scalar_counter(ws.counters, 7) * 4u;
+    for (unsigned u = blockIdx.x; u < n_units; u += gridDim.x) {
+        const int* desc = ws.chunks + 4 * (long long)(u >> 2);
+        const int bucket = __builtin_amdgcn_readfirstlane(desc[0]);
+        const int begin = __builtin_amdgcn_readfirstlane(desc[1]) + 16 * (int)(u & 3);
+        const int cnt = __builtin_amdgcn_readfirstlane(desc[2]) - begin;       // items of this wave (may be <= 0)
+        if (cnt <= 0) continue;
+        const int ch = bucket >> 9, blk = bucket & 511;
+        const int rows = __builtin_amdgcn_readfirstlane(dict.block_rows[blk]);
+        const int my_tc = ws.items[begin + (slot < cnt ? slot : 0)];
+        bool nz = false;
+#pragma unroll 4
+        for (int i = 0; i < kFilterGroup; ++i) {
+            const int tci = __builtin_amdgcn_readlane(my_tc, i);
+            const double v = ws.r[(long long)tci * N + lane];
+            s_r[i * kStageStride + lane] = v;
+            const bool any = __ballot(v != 0.0) != 0;
+            if (slot == i) nz = any;
+        }
+        __syncthreads();
+        float rb[16];
+        const double ss = load_b_operand(rb, s_r, lane);
+        const float window = 2.0f * (kFilterSlack * (float)__builtin_sqrt(ss) + kFilterAbs);
+        const float4* tiles = (const float4*)(dict.detail_f32 + ((long long)ch * dict.num_base + blk) * kBlockFilterTiles * 1024);
+#pragma unroll
+        for (int tile = 0; tile < kBlockFilterTiles; ++tile) {
+            const f32x4 acc = mfma_tile(tiles + tile * 256, rb, lane);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) s_p[(tile * 16 + sub * 4 + v) * kFilterGroup + slot] = acc[v];
+        }
+        __syncthreads();
+        float pv[16];
+        float mx = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            pv[i] = fabsf(s_p[(4 * i + sub) * kFilterGroup + slot]);
+            mx = fmaxf(mx, pv[i]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float thr = mx - window;
+        unsigned mask = 0;
+        if (slot < cnt && nz) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (!(pv[i] < thr) && 4 * i + sub < rows) mask |= 1u << i;
+        }
+        double best_val = 0.0;
+        int best_row = -1;
+        const double* block = dict.detail + ((long long)ch * dict.detail_rows + __builtin_amdgcn_readfirstlane(dict.block_row_off[blk])) * N;
+        while (mask) {
+            const int i = __builtin_ctz(mask);
+            mask &= mask - 1;
+            const int a = 4 * i + sub;
+            const double p = dot_exact(block + (long long)a * N, s_r + slot * kStageStride);
+            if (__builtin_fabs(p) > __builtin_fabs(best_val)) { best_val = p; best_row = a; }
+        }
+        keep_better(best_val, best_row, __shfl_xor(best_val, 16), __shfl_xor(best_row, 16));
+        keep_better(best_val, best_row, __shfl_xor(best_val, 32), __shfl_xor(best_row, 32));
+        if (sub == 0 && slot < cnt) {
+            ws.cand_val[(long long)(begin + slot) * kMaxRowParts] = best_val;
+            ws.cand_row[(long long)(begin + slot) * kMaxRowParts] = best_row;
+        }
+        __syncthreads();
+    }
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -1028,9 +1139,10 @@ int enqueue_pursuit(const DictDevice& dict, const Workspace& ws, const FrameInpu
     hipStream_t s = static_cast<hipStream_t>(stream_);
     hipStream_t side = static_cast<hipStream_t>(side_stream_);
     hipEvent_t ev_fork = static_cast<hipEvent_t>(fork_event_), ev_join = static_cast<hipEvent_t>(join_event_);
-    const bool forked = side != nullptr && ev_fork != nullptr && ev_join != nullptr;
+    const bool forked = side != nullptr && ev_fork != nullptr && ev_join != nullptr && parts >= 1;
     if (n < 1 || n > ws.cap) return (int)hipErrorInvalidValue;
-    const bool filtered = parts < 1;          // base rows (+ block 0) through the MFMA filter instead of the full sweep
+    const bool filtered = parts < 1;          // sweeps through the MFMA filter instead of correlating every row exactly
+    if (filtered) row_parts = 1;
     if (parts < 1) parts = 1;
     if (parts > kMaxParts) parts = kMaxParts;
     if (row_parts < 1) row_parts = 1;
@@ -1063,7 +1175,7 @@ int enqueue_pursuit(const DictDevice& dict, const Workspace& ws, const FrameInpu
         }
         if (base_events) (void)hipEventRecord(static_cast<hipEvent_t>(base_events[2 * step]), s);
         if (filtered)
-            hipLaunchKernelGGL(mp_filter_kernel, dim3(clampu(lists * (unsigned)((per_list + 31) / 32), 512u)), dim3(128), 0, s, ws,
+            hipLaunchKernelGGL(mp_filter_kernel, dim3(clampu(lists * (unsigned)((per_list + 15) / 16), 768u)), dim3(256), 0, s, ws,
                                dict, cur, step > 0 ? 1 : 0);
         else
             hipLaunchKernelGGL(mp_base_kernel, dim3(clampu(max_groups * (unsigned)(parts + 1), slots)), dim3(64), 0, s, ws, dict,
@@ -1073,6 +1185,8 @@ int enqueue_pursuit(const DictDevice& dict, const Workspace& ws, const FrameInpu
             if (forked) {
                 (void)hipEventRecord(ev_join, side);
                 (void)hipStreamWaitEvent(s, ev_join, 0);
+            } else if (filtered) {
+                hipLaunchKernelGGL(mp_detail_filter_kernel, dim3(clampu(max_groups * 4u, 3072u)), dim3(64), 0, s, ws, dict);
             } else {
                 hipLaunchKernelGGL(mp_detail_kernel, dim3(clampu(max_groups * (unsigned)row_parts, slots)), dim3(64), 0, s, ws,
                                    dict, row_parts, (int)slots, ws.cand_val);
