@@ -42,6 +42,7 @@ struct DictDevice {
     const double* detail;            // [3][detail_rows][64] row-major (+1 zero row at the very end)
     long long detail_rows;           // rows per channel (31 622)
     const int32_t* block_rows;       // [num_base]
+    int block0_rows;                 // block_rows[0] (host copy)
     const int32_t* block_row_off;    // [num_base+1]
     // single-precision copies for the filter pass, in MFMA operand order (host_dictionary.h: filter_tiles)
     const float* base_f32;           // [kBaseFilterTiles][1024]: base rows 0..511 (510 + 2 zero rows)
@@ -56,6 +57,7 @@ struct Workspace {
     int* part_idx;                   // [cap][kMaxParts]
     double* cand0_val;               // [cap] best projection on DetailBasis[0] (if unlocked)
     int* cand0_row;                  // [cap]
+    float* approx_max;               // [cap] filter pass: largest approximate projection over base rows + block 0
     int* prev_id;                    // [cap]
     int* nblk;                       // [cap] entries in blk_list
     int* extra_rows;                 // [cap] rows appended after the base part (duplicates included)

@@ -18,6 +18,19 @@
 
 namespace mpc {
 
+// Phase stamps for tools/filter_probe.hip (-DMPC_STAMPS): shader clocks spent by thread 0 of each block between
+// consecutive MPC_STAMP points, summed over blocks.  Compiled out of the product library.
+#ifdef MPC_STAMPS
+__device__ unsigned long long g_stamps[16];
+#define MPC_STAMP_BEGIN() unsigned long long stamp_acc_[12] = {0}; unsigned long long stamp_last_ = __builtin_readcyclecounter();
+#define MPC_STAMP(k) { const unsigned long long now_ = __builtin_readcyclecounter(); stamp_acc_[k] += now_ - stamp_last_; stamp_last_ = now_; }
+#define MPC_STAMP_END() if (threadIdx.x == 0) { for (int k_ = 0; k_ < 12; ++k_) atomicAdd(&g_stamps[k_], stamp_acc_[k_]); }
+#else
+#define MPC_STAMP_BEGIN()
+#define MPC_STAMP(k)
+#define MPC_STAMP_END()
+#endif
+
 namespace {
 
 typedef const double __attribute__((address_space(4))) * scalar_f64_ptr;   // constant address space: forces s_load
@@ -161,7 +174,10 @@ __device__ __forceinline__ int entry_block(unsigned e) { return (int)(e & 0x1FFu
 __device__ __forceinline__ int entry_rows(unsigned e) { return (int)((e >> 9) & 0x3Fu); }
 __device__ __forceinline__ bool entry_repeat(unsigned e) { return (e & 0x8000u) != 0; }
 __device__ __forceinline__ bool entry_is_item(unsigned e) { return !entry_repeat(e) && entry_block(e) != 0; }   // bucketed sweep
-__device__ __forceinline__ bool entry_is_first_block0(unsigned e) { return !entry_repeat(e) && entry_block(e) == 0; }
+
+// nblk[tc]: entries in blk_list (low byte) | 0x100 once block 0 (DetailBasis[0]) is unlocked
+__device__ __forceinline__ int nblk_count(int v) { return v & 0xFF; }
+__device__ __forceinline__ bool nblk_has0(int v) { return (v & 0x100) != 0; }
 
 __device__ __forceinline__ unsigned scalar_counter(const unsigned* counters, int i)
 {
@@ -251,9 +267,7 @@ __global__ __launch_bounds__(64, 3) void mp_base_kernel(const Workspace ws, cons
         } else {
             bool has0 = false;
             if (valid) {
-                const int nb = ws.nblk[tc];
-                for (int i = 0; i < nb; ++i)
-                    if (entry_is_first_block0(ws.blk_list[(long long)tc * kMaxDeviceK + i])) has0 = true;
+                has0 = nblk_has0(ws.nblk[tc]);
             }
             if (!__ballot(has0)) continue;
             double r[N];
@@ -283,6 +297,10 @@ __global__ __launch_bounds__(64, 3) void mp_base_kernel(const Workspace ws, cons
 //   * let j* be the row Select() returns (lowest index with maximal exact |p|) and j~ the approximate maximum:
 //     approx|p_j*| >= |p_j*| - E >= |p_j~| - E >= approx|p_j~| - 2E, so j* is kept -- as is every row tying with it.
 //   * overflow / NaN anywhere makes the comparison `approx < threshold` false: the row is kept and evaluated.
+//   * the threshold may use the largest approximation over ANY subset of the rows the tile-channel can choose from:
+//     a smaller maximum only lowers it.  Base rows and block 0 share one (mp_filter_kernel), which it also leaves in
+//     approx_max[] for the detail blocks (mp_detail_filter_kernel): a block whose best row is far below the base
+//     maximum yields no survivor at all and reports "none" (index -1), which the finish kernel skips.
 //   * rows that are +-copies of an earlier row (base row 509 = -row 0) are zero in the f32 copy: they tie with the
 //     earlier row exactly and can never be returned (host_dictionary.cpp: filter_tiles).
 // --------------------------------------------------------------------------------------------------
@@ -295,25 +313,6 @@ constexpr int kFilterRows = 16 * (kBaseFilterTiles + kBlockFilterTiles);  // 576
 constexpr int kStageStride = N + 1;                                       // doubles per staged residual (+1: bank spread)
 constexpr float kFilterSlack = 0x1p-17f;
 constexpr float kFilterAbs = 0x1p-140f;
-
-// the reference's dot product of one dictionary row with a residual staged in LDS
-__device__ __forceinline__ double dot_exact(const double* row, const double* r_lds)
-{
-    const double2* src = (const double2*)row;
-    double tot = 0.0;
-#pragma unroll 1
-    for (int b = 0; b < N / 2; b += 8) {                     // 8 row loads in flight: bounded register use
-        double2 v[8];
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) v[jj] = src[b + jj];
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
-            tot += v[jj].x * r_lds[2 * (b + jj)];
-            tot += v[jj].y * r_lds[2 * (b + jj) + 1];
-        }
-    }
-    return tot;
-}
 
 // B operand of the 16x16x4 MFMAs for 16 staged residuals: lane (slot = l & 15, kg = l >> 4) holds r~[slot][4kk + kg];
 // also returns |r~[slot]|^2 (summed over the four kg lanes)
@@ -331,22 +330,8 @@ __device__ __forceinline__ double load_b_operand(float (&rb)[16], const double* 
     return ss;
 }
 
-// 16 rows x 16 residuals: one f32 tile of the filter copy against the B operand
-__device__ __forceinline__ f32x4 mfma_tile(const float4* tile, const float (&rb)[16], int lane)
-{
-    float4 av[4];
-#pragma unroll
-    for (int kq = 0; kq < 4; ++kq) av[kq] = tile[kq * 64 + lane];
-    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int kq = 0; kq < 4; ++kq) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kq].x, rb[4 * kq + 0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kq].y, rb[4 * kq + 1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kq].z, rb[4 * kq + 2], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kq].w, rb[4 * kq + 3], acc, 0, 0, 0);
-    }
-    return acc;
-}
+// mask of the lowest n bits (n may be <= 0 or >= 32)
+__device__ __forceinline__ unsigned low_bits(int n) { return n <= 0 ? 0u : (n >= 32 ? 0xFFFFFFFFu : (1u << n) - 1u); }
 
 // keep the better of two (value, row) results of disjoint row sets: larger |value|, on a tie the lower row
 __device__ __forceinline__ void keep_better(double& v, int& i, double ov, int oi)
@@ -357,14 +342,134 @@ __device__ __forceinline__ void keep_better(double& v, int& i, double ov, int oi
     }
 }
 
+// Exact evaluation of the surviving rows, cooperatively by one wave.  Lane (slot, sub) holds its survivors as bit
+// masks (bit i of segment s = row off_s + 4i + sub of rows_s).  Per round the first 16 lanes that still have one
+// each put up their lowest survivor; the wave then works lane = pixel: one coalesced 512-byte read per row, the
+// 64 products row[j]*r[j] (rounded to double like the reference's `l*r`) go to LDS, and lane k adds up the
+// products of survivor k in j order -- exactly the reference's `tot += l*r` chain.  A lane's survivors come up in
+// ascending row order, so its strict '>' keeps the first maximum.
+constexpr int kCandRound = 16;
+struct CandLds {
+    double prod[kCandRound * kStageStride];
+    double res[kCandRound];
+};
+
+// LDS hand-off between lanes of ONE wave: DS operations of a wave execute in issue order, so all that is needed is
+// that the compiler keeps the order and the data has landed; no vector-memory wait (a fence would also drain the
+// prefetched global loads)
+__device__ __forceinline__ void wave_lds_sync()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+__device__ __forceinline__ void evaluate_survivors(CandLds& lds, const double* stage, int lane, unsigned mask0, unsigned mask1,
+                                                   int off0, int off1, const double* rows0, const double* rows1, double& v0,
+                                                   int& i0, double& v1, int& i1)
+{
+    const int slot = lane & 15, sub = lane >> 4;
+    v0 = 0.0; v1 = 0.0;
+    i0 = -1; i1 = -1;
+    for (;;) {
+        const bool pending = (mask0 | mask1) != 0;
+        const unsigned long long votes = __ballot(pending);
+        if (!votes) break;
+        const int rank = __popcll(votes & ((1ULL << lane) - 1ULL));
+        const bool active = pending && rank < kCandRound;
+        int seg = 0, a = 0;
+        unsigned long long row_addr = 0;
+        if (active) {
+            if (mask0) { const int i = __builtin_ctz(mask0); mask0 &= mask0 - 1; a = off0 + 4 * i + sub; }
+            else { const int i = __builtin_ctz(mask1); mask1 &= mask1 - 1; a = off1 + 4 * i + sub; seg = 1; }
+            row_addr = (unsigned long long)(uintptr_t)((seg ? rows1 : rows0) + (long long)a * N);
+        }
+        int n = __popcll(votes);
+        if (n > kCandRound) n = kCandRound;
+        unsigned long long left = votes;
+        for (int k0 = 0; k0 < n; k0 += 4) {                     // four row reads in flight; slots past n repeat the last row
+            double x[4], y[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int src = __builtin_ctzll(left);         // wave-uniform: the lane that put up survivor k0 + kk
+                if (left & (left - 1)) left &= left - 1;
+                const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)row_addr, src);
+                const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(row_addr >> 32), src);
+                const double* row = (const double*)(uintptr_t)(((unsigned long long)hi << 32) | lo);
+                x[kk] = row[lane];
+                y[kk] = stage[(src & 15) * kStageStride + lane];
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) lds.prod[(k0 + kk) * kStageStride + lane] = x[kk] * y[kk];
+        }
+        wave_lds_sync();
+        if (lane < n) {
+            const double* pr = lds.prod + lane * kStageStride;
+            double tot = 0.0;
+#pragma unroll
+            for (int j = 0; j < N; ++j) tot += pr[j];
+            lds.res[lane] = tot;
+        }
+        wave_lds_sync();
+        if (active) {
+            const double p = lds.res[rank];
+            if (seg == 0) { if (__builtin_fabs(p) > __builtin_fabs(v0)) { v0 = p; i0 = a; } }
+            else if (__builtin_fabs(p) > __builtin_fabs(v1)) { v1 = p; i1 = a; }
+        }
+        wave_lds_sync();
+    }
+    (void)slot;
+}
+
 }  // namespace
+
+// What the filter kernels touch, and nothing else: passing the whole Workspace / DictDevice keeps ~100 SGPRs of
+// pointers alive and spills them into VGPR lanes.
+struct FilterArgs {
+    const unsigned* counters_in;     // ws.counters
+    unsigned* counters_out;          // same array (next step's active counts are reset here)
+    const int* act[3];               // this step's active lists
+    const double* r;
+    const int* nblk;
+    double* part_val;
+    int* part_idx;
+    double* cand0_val;
+    int* cand0_row;
+    float* approx_max;               // out: largest approximation over base + block 0, per tile-channel
+    const double* base;              // dictionary, double
+    const double* block0[3];         // DetailBasis[0] of each channel, double
+    const float* base_f32;           // filter copies
+    const float* block0_f32[3];
+    int num_base, rows0;
+};
+
+struct DetailFilterArgs {
+    const unsigned* counters;
+    const int* chunks;
+    const int* items;
+    const double* r;
+    double* cand_val;
+    int* cand_row;
+    const float* approx_max;         // written by mp_filter_kernel earlier in the step
+    const double* detail;            // [3][detail_rows][64]
+    long long detail_rows;
+    const float* detail_f32;
+    const int32_t* block_rows;
+    const int32_t* block_row_off;
+    int num_base;
+};
 
 // Base rows and (steps > 0) the 63 rows of DetailBasis[0], which the DC atom unlocks for nearly every tile-channel:
 // they ride along as four more tiles with their own threshold and their own result slot.
 // Block = 256 threads = 4 waves, 16 tile-channels of one channel's active list; 47 KiB of LDS, three blocks per CU.
-__global__ __launch_bounds__(256, 3) void mp_filter_kernel(const Workspace ws, const DictDevice dict, int cur, int with_detail0)
+#ifndef MPC_FILTER_OCC
+#define MPC_FILTER_OCC 3
+#endif
+#ifndef MPC_FILTER_AHEAD
+#define MPC_FILTER_AHEAD 2
+#endif
+__global__ __launch_bounds__(256, MPC_FILTER_OCC) void mp_filter_kernel(const FilterArgs fa, int cur, int with_detail0)
 {
-    __shared__ float s_p[kFilterRows * kFilterGroup];        // approximate projections [row][slot]
+    __shared__ __attribute__((aligned(16))) float s_p[kFilterRows * kFilterGroup];   // approximate projections [row][slot]
+    static_assert(sizeof(float) * kFilterRows * kFilterGroup >= 4 * sizeof(CandLds), "product buffers overlay s_p");
     __shared__ double s_r[kFilterGroup * kStageStride];      // the 16 residuals
     __shared__ float s_max[2][4][kFilterGroup];              // [base | block 0][wave][slot]
     __shared__ double s_val[2][4][kFilterGroup];
@@ -373,41 +478,69 @@ __global__ __launch_bounds__(256, 3) void mp_filter_kernel(const Workspace ws, c
     __shared__ int s_flags[kFilterGroup];                    // bit 0: residual has a non-zero element; bit 1: block 0 unlocked
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int slot = lane & 15, sub = lane >> 4;
-    if (blockIdx.x == 0 && t < 3) ws.counters[(cur ^ 1) * 3 + t] = 0;      // next step's active counts
-    const int n0 = (int)scalar_counter(ws.counters, cur * 3 + 0), n1 = (int)scalar_counter(ws.counters, cur * 3 + 1),
-              n2 = (int)scalar_counter(ws.counters, cur * 3 + 2);
+    if (blockIdx.x == 0 && t < 3) fa.counters_out[(cur ^ 1) * 3 + t] = 0;      // next step's active counts
+    const int n0 = (int)scalar_counter(fa.counters_in, cur * 3 + 0), n1 = (int)scalar_counter(fa.counters_in, cur * 3 + 1),
+              n2 = (int)scalar_counter(fa.counters_in, cur * 3 + 2);
     const int g0 = (n0 + kFilterGroup - 1) / kFilterGroup, g1 = (n1 + kFilterGroup - 1) / kFilterGroup,
               g2 = (n2 + kFilterGroup - 1) / kFilterGroup;
     const int ntiles = kBaseFilterTiles + (with_detail0 ? kBlockFilterTiles : 0);
-    const int rows0 = dict.block_rows[0];
-    for (int u = blockIdx.x; u < g0 + g1 + g2; u += gridDim.x) {
-        const int ch = u < g0 ? 0 : (u < g0 + g1 ? 1 : 2);
-        const int group = u - (ch == 0 ? 0 : (ch == 1 ? g0 : g0 + g1));
-        const int n_act = ch == 0 ? n0 : (ch == 1 ? n1 : n2);
-        const int* act = ws.act[cur][ch];
+    const int rows0 = fa.rows0;
+    const int total_units = g0 + g1 + g2;
+    const int* const act0 = fa.act[0];
+    const int* const act1 = fa.act[1];
+    const int* const act2 = fa.act[2];
+    // what a unit stages, fetched one unit ahead: residual element `lane` of the wave's four tile-channels.  In two
+    // stages (list entries, then what they point at), issued from inside the MFMA loop after the last tile read so
+    // that nothing later in program order has to wait for them (vector loads return in order).
+    double pre_v0 = 0.0, pre_v1 = 0.0, pre_v2 = 0.0, pre_v3 = 0.0;
+    int pre_id0 = 0, pre_id1 = 0, pre_id2 = 0, pre_id3 = 0;          // list entries (tile-channels), -1 past the end
+    int pre_nb0 = 0, pre_nb1 = 0, pre_nb2 = 0, pre_nb3 = 0;
+#define MPC_FETCH_IDS(unit_)                                                                                   \
+    if ((unit_) < total_units) {                                                                               \
+        const int c_ = __builtin_amdgcn_readfirstlane((unit_) < g0 ? 0 : ((unit_) < g0 + g1 ? 1 : 2));         \
+        const int first_ = ((unit_) - (c_ == 0 ? 0 : (c_ == 1 ? g0 : g0 + g1))) * kFilterGroup + wave * 4;     \
+        const int n_ = c_ == 0 ? n0 : (c_ == 1 ? n1 : n2);                                                     \
+        const int* list_ = c_ == 0 ? act0 : (c_ == 1 ? act1 : act2);                                           \
+        pre_id0 = first_ + 0 < n_ ? list_[first_ + 0] : -1;                                                    \
+        pre_id1 = first_ + 1 < n_ ? list_[first_ + 1] : -1;                                                    \
+        pre_id2 = first_ + 2 < n_ ? list_[first_ + 2] : -1;                                                    \
+        pre_id3 = first_ + 3 < n_ ? list_[first_ + 3] : -1;                                                    \
+    }
+#define MPC_FETCH_ROW(v_, nb_, id_)                                                                            \
+    v_ = (id_) >= 0 ? fa.r[(long long)(id_) * N + lane] : 0.0;                                                 \
+    nb_ = (id_) >= 0 ? fa.nblk[(id_)] : 0;
+#define MPC_FETCH_ROWS(unit_)                                                                                  \
+    if ((unit_) < total_units) {                                                                               \
+        MPC_FETCH_ROW(pre_v0, pre_nb0, pre_id0)                                                                \
+        MPC_FETCH_ROW(pre_v1, pre_nb1, pre_id1)                                                                \
+        MPC_FETCH_ROW(pre_v2, pre_nb2, pre_id2)                                                                \
+        MPC_FETCH_ROW(pre_v3, pre_nb3, pre_id3)                                                                \
+    }
+    MPC_FETCH_IDS((int)blockIdx.x)
+    MPC_FETCH_ROWS((int)blockIdx.x)
+    MPC_STAMP_BEGIN()
+    for (int u = blockIdx.x; u < total_units; u += gridDim.x) {
+        const int ch = __builtin_amdgcn_readfirstlane(u < g0 ? 0 : (u < g0 + g1 ? 1 : 2));
 
-        // ---- stage the 16 residuals: wave w brings rows 4w..4w+3, lane = pixel (one coalesced 512-byte read each)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int sl = wave * 4 + i;
-            const int pos = group * kFilterGroup + sl;
-            const bool ok = pos < n_act;
-            const int tc = act[ok ? pos : group * kFilterGroup];
-            const double v = ws.r[(long long)tc * N + lane];
-            s_r[sl * kStageStride + lane] = v;
-            const bool nz = __ballot(v != 0.0) != 0;
-            if (lane == 0) {
-                bool has0 = false;
-                if (with_detail0 && ok) {
-                    const int nb = ws.nblk[tc];
-                    for (int k = 0; k < nb; ++k)
-                        if (entry_is_first_block0(ws.blk_list[(long long)tc * kMaxDeviceK + k])) has0 = true;
-                }
-                s_tc[sl] = ok ? tc : -1;
-                s_flags[sl] = (nz ? 1 : 0) | (has0 ? 2 : 0);
-            }
+        // ---- stage the 16 residuals: wave w brings rows 4w..4w+3, lane = pixel (one coalesced 512-byte read each);
+        //      they were fetched while the previous unit was being worked on
+#define MPC_STAGE(i_, v_, nb_, id_)                                                                            \
+        {                                                                                                      \
+            const int sl_ = wave * 4 + (i_);                                                                   \
+            s_r[sl_ * kStageStride + lane] = v_;                                                               \
+            const bool nz_ = __ballot(v_ != 0.0) != 0;                                                         \
+            if (lane == 0) {                                                                                   \
+                s_tc[sl_] = id_;                                                                               \
+                s_flags[sl_] = (nz_ ? 1 : 0) | ((with_detail0 && nblk_has0(nb_)) ? 2 : 0);                     \
+            }                                                                                                  \
         }
+        MPC_STAGE(0, pre_v0, pre_nb0, pre_id0)
+        MPC_STAGE(1, pre_v1, pre_nb1, pre_id1)
+        MPC_STAGE(2, pre_v2, pre_nb2, pre_id2)
+        MPC_STAGE(3, pre_v3, pre_nb3, pre_id3)
+        MPC_STAMP(0)
         __syncthreads();
+        MPC_STAMP(1)
 
         // ---- (1) approximate projections; wave w takes tiles w, w+4, ...
         float window;
@@ -415,71 +548,90 @@ __global__ __launch_bounds__(256, 3) void mp_filter_kernel(const Workspace ws, c
             float rb[16];
             const double ss = load_b_operand(rb, s_r, lane);
             window = 2.0f * (kFilterSlack * (float)__builtin_sqrt(ss) + kFilterAbs);
-            const float* tiles0 = dict.detail_f32 + (long long)ch * dict.num_base * kBlockFilterTiles * 1024;
-            for (int tile = wave; tile < ntiles; tile += 4) {
-                const float4* a = (const float4*)(tile < kBaseFilterTiles ? dict.base_f32 + tile * 1024
-                                                                          : tiles0 + (tile - kBaseFilterTiles) * 1024);
-                const f32x4 acc = mfma_tile(a, rb, lane);
+            const float* tiles0 = ch == 0 ? fa.block0_f32[0] : (ch == 1 ? fa.block0_f32[1] : fa.block0_f32[2]);
+            auto tile_ptr = [&](int tile) {
+                return (const float4*)(tile < kBaseFilterTiles ? fa.base_f32 + tile * 1024 : tiles0 + (tile - kBaseFilterTiles) * 1024);
+            };
+            // nine (eight at step 0) tiles per wave, kAhead tile reads (4 x 16 B per lane each) in flight ahead of the MFMAs
+            constexpr int kPerWave = (kBaseFilterTiles + kBlockFilterTiles) / 4, kAhead = MPC_FILTER_AHEAD;
+            float4 av[kAhead][4];
 #pragma unroll
-                for (int v = 0; v < 4; ++v) s_p[(tile * 16 + sub * 4 + v) * kFilterGroup + slot] = acc[v];
+            for (int i = 0; i < kAhead; ++i) {
+                const float4* a = tile_ptr(wave + 4 * i);
+#pragma unroll
+                for (int kq = 0; kq < 4; ++kq) av[i][kq] = a[kq * 64 + lane];
+            }
+#pragma unroll
+            for (int i = 0; i < kPerWave; ++i) {
+                const int tile = wave + 4 * i;
+                if (i == 2) { MPC_FETCH_IDS(u + (int)gridDim.x) }
+                if (i == 6) { MPC_FETCH_ROWS(u + (int)gridDim.x) }
+                if (tile < ntiles) {
+                    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                    for (int kq = 0; kq < 4; ++kq) {
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i % kAhead][kq].x, rb[4 * kq + 0], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i % kAhead][kq].y, rb[4 * kq + 1], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i % kAhead][kq].z, rb[4 * kq + 2], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i % kAhead][kq].w, rb[4 * kq + 3], acc, 0, 0, 0);
+                    }
+                    if (i + kAhead < kPerWave && tile + 4 * kAhead < ntiles) {
+                        const float4* a = tile_ptr(tile + 4 * kAhead);
+#pragma unroll
+                        for (int kq = 0; kq < 4; ++kq) av[i % kAhead][kq] = a[kq * 64 + lane];
+                    }
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) s_p[(tile * 16 + sub * 4 + v) * kFilterGroup + slot] = acc[v];
+                }
             }
         }
+        MPC_STAMP(2)
         __syncthreads();
+        MPC_STAMP(3)
 
         // ---- (2) largest approximation per tile-channel.  Wave w scans base rows [128w, 128w+128) and block-0 rows
         //          [16w, 16w+16); lane (slot, sub) takes every fourth row (conflict-free LDS reads) and keeps them.
-        float pb[32], pd[4];
         {
             float mb = 0.0f, md = 0.0f;
 #pragma unroll
-            for (int i = 0; i < 32; ++i) {
-                pb[i] = fabsf(s_p[(wave * 128 + 4 * i + sub) * kFilterGroup + slot]);
-                mb = fmaxf(mb, pb[i]);
-            }
+            for (int i = 0; i < 32; ++i) mb = fmaxf(mb, fabsf(s_p[(wave * 128 + 4 * i + sub) * kFilterGroup + slot]));
+            if (with_detail0) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                pd[i] = with_detail0 ? fabsf(s_p[(16 * kBaseFilterTiles + wave * 16 + 4 * i + sub) * kFilterGroup + slot]) : 0.0f;
-                md = fmaxf(md, pd[i]);
+                for (int i = 0; i < 4; ++i) md = fmaxf(md, fabsf(s_p[(16 * kBaseFilterTiles + wave * 16 + 4 * i + sub) * kFilterGroup + slot]));
             }
             mb = fmaxf(mb, __shfl_xor(mb, 16)); mb = fmaxf(mb, __shfl_xor(mb, 32));
             md = fmaxf(md, __shfl_xor(md, 16)); md = fmaxf(md, __shfl_xor(md, 32));
-            if (sub == 0) { s_max[0][wave][slot] = mb; s_max[1][wave][slot] = md; }
+            if (sub == 0) { s_max[0][wave][slot] = mb; s_max[1][wave][slot] = (s_flags[slot] & 2) ? md : 0.0f; }
         }
+        MPC_STAMP(4)
         __syncthreads();
-        const float thr_b = fmaxf(fmaxf(s_max[0][0][slot], s_max[0][1][slot]), fmaxf(s_max[0][2][slot], s_max[0][3][slot])) - window;
-        const float thr_d = fmaxf(fmaxf(s_max[1][0][slot], s_max[1][1][slot]), fmaxf(s_max[1][2][slot], s_max[1][3][slot])) - window;
+        MPC_STAMP(5)
+        const float top = fmaxf(fmaxf(fmaxf(s_max[0][0][slot], s_max[0][1][slot]), fmaxf(s_max[0][2][slot], s_max[0][3][slot])),
+                                fmaxf(fmaxf(s_max[1][0][slot], s_max[1][1][slot]), fmaxf(s_max[1][2][slot], s_max[1][3][slot])));
+        const float thr_b = top - window, thr_d = thr_b;     // one threshold for base rows and block 0
 
-        // ---- (3) the rows that can be the maximum, ascending, in the reference's arithmetic
+        // ---- (3) the rows that can be the maximum (second read of the approximations), then their exact values
         const int tc = s_tc[slot];
         const int flags = s_flags[slot];
         unsigned mask_b = 0, mask_d = 0;
         if (tc >= 0 && (flags & 1)) {                       // an all-zero residual projects to 0 everywhere: index -1
 #pragma unroll
             for (int i = 0; i < 32; ++i)
-                if (!(pb[i] < thr_b) && wave * 128 + 4 * i + sub < dict.num_base) mask_b |= 1u << i;
+                if (!(fabsf(s_p[(wave * 128 + 4 * i + sub) * kFilterGroup + slot]) < thr_b)) mask_b |= 1u << i;
+            mask_b &= low_bits((fa.num_base - wave * 128 - sub + 3) >> 2);      // rows past the dictionary's end (zero pads)
             if (flags & 2) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    if (!(pd[i] < thr_d) && wave * 16 + 4 * i + sub < rows0) mask_d |= 1u << i;
+                    if (!(fabsf(s_p[(16 * kBaseFilterTiles + wave * 16 + 4 * i + sub) * kFilterGroup + slot]) < thr_d)) mask_d |= 1u << i;
+                mask_d &= low_bits((rows0 - wave * 16 - sub + 3) >> 2);
             }
         }
-        double bv = 0.0, dv = 0.0;
-        int bi = -1, di = -1;
-        const double* r_lds = s_r + slot * kStageStride;
-        while (mask_b) {
-            const int i = __builtin_ctz(mask_b);
-            mask_b &= mask_b - 1;
-            const int a = wave * 128 + 4 * i + sub;
-            const double p = dot_exact(dict.base + (long long)a * N, r_lds);
-            if (__builtin_fabs(p) > __builtin_fabs(bv)) { bv = p; bi = a; }
-        }
-        while (mask_d) {
-            const int i = __builtin_ctz(mask_d);
-            mask_d &= mask_d - 1;
-            const int a = wave * 16 + 4 * i + sub;
-            const double p = dot_exact(dict.detail + ((long long)ch * dict.detail_rows + a) * N, r_lds);
-            if (__builtin_fabs(p) > __builtin_fabs(dv)) { dv = p; di = a; }
-        }
+        __syncthreads();                                    // every wave is past its last read of s_p: its space now takes the products
+        double bv, dv;
+        int bi, di;
+        evaluate_survivors(reinterpret_cast<CandLds*>(s_p)[wave], s_r, lane, mask_b, mask_d, wave * 128, wave * 16, fa.base,
+                           ch == 0 ? fa.block0[0] : (ch == 1 ? fa.block0[1] : fa.block0[2]), bv, bi, dv, di);
+        MPC_STAMP(6)
         // the four lanes of a slot hold interleaved rows: combine by (|value|, lower row)
         keep_better(bv, bi, __shfl_xor(bv, 16), __shfl_xor(bi, 16));
         keep_better(bv, bi, __shfl_xor(bv, 32), __shfl_xor(bi, 32));
@@ -489,7 +641,9 @@ __global__ __launch_bounds__(256, 3) void mp_filter_kernel(const Workspace ws, c
             s_val[0][wave][slot] = bv; s_idx[0][wave][slot] = bi;
             s_val[1][wave][slot] = dv; s_idx[1][wave][slot] = di;
         }
+        MPC_STAMP(7)
         __syncthreads();
+        MPC_STAMP(8)
         if (t < kFilterGroup && tc >= 0) {                  // t == slot; waves hold ascending row ranges
             bv = s_val[0][0][t]; bi = s_idx[0][0][t];
             dv = s_val[1][0][t]; di = s_idx[1][0][t];
@@ -497,15 +651,23 @@ __global__ __launch_bounds__(256, 3) void mp_filter_kernel(const Workspace ws, c
                 keep_better(bv, bi, s_val[0][k][t], s_idx[0][k][t]);
                 keep_better(dv, di, s_val[1][k][t], s_idx[1][k][t]);
             }
-            ws.part_val[(long long)tc * kMaxParts] = bv;
-            ws.part_idx[(long long)tc * kMaxParts] = bi;
+            fa.part_val[(long long)tc * kMaxParts] = bv;
+            fa.part_idx[(long long)tc * kMaxParts] = bi;
+            fa.approx_max[tc] = top;
             if (flags & 2) {
-                ws.cand0_val[tc] = dv;
-                ws.cand0_row[tc] = di;
+                fa.cand0_val[tc] = dv;
+                fa.cand0_row[tc] = di;
             }
         }
+        MPC_STAMP(9)
         __syncthreads();
+        MPC_STAMP(10)
     }
+    MPC_STAMP_END()
+#undef MPC_FETCH_IDS
+#undef MPC_FETCH_ROW
+#undef MPC_FETCH_ROWS
+#undef MPC_STAGE
 }
 
 // Row range `part` of `row_parts` of a block with `rows` rows: [lo, hi)
@@ -575,39 +737,56 @@ __global__ __launch_bounds__(64, 3) void mp_detail_kernel(const Workspace ws, co
 // filtered detail sweep: the same filter for the bucketed detail blocks.  One wave per 16 items of a chunk
 // (<= 64 items of one (channel, block) bucket): 64 x 16 approximations (4 tiles, 64 MFMAs), then lane (slot, sub)
 // scans every fourth row of its item and the survivors are evaluated exactly.  12 KiB of LDS per wave.
-__global__ __launch_bounds__(64, 4) void mp_detail_filter_kernel(const Workspace ws, const DictDevice dict)
+__global__ __launch_bounds__(64) void mp_detail_filter_kernel(const DetailFilterArgs da)
 {
-    __shared__ float s_p[64 * kFilterGroup];                 // approximate projections [row][slot]
+    __shared__ __attribute__((aligned(16))) char s_buf[sizeof(CandLds)];   // approximations [row][slot], then the products
+    static_assert(sizeof(CandLds) >= sizeof(float) * 64 * kFilterGroup, "s_p fits");
     __shared__ double s_r[kFilterGroup * kStageStride];
+    float* s_p = reinterpret_cast<float*>(s_buf);
+    CandLds& s_cand = *reinterpret_cast<CandLds*>(s_buf);
     const int lane = threadIdx.x;
     const int slot = lane & 15, sub = lane >> 4;
-    const unsigned n_units = scalar_counter(ws.counters, 7) * 4u;
+    const unsigned n_units = scalar_counter(da.counters, 7) * 4u;
     for (unsigned u = blockIdx.x; u < n_units; u += gridDim.x) {
-        const int* desc = ws.chunks + 4 * (long long)(u >> 2);
+        const int* desc = da.chunks + 4 * (long long)(u >> 2);
         const int bucket = __builtin_amdgcn_readfirstlane(desc[0]);
         const int begin = __builtin_amdgcn_readfirstlane(desc[1]) + 16 * (int)(u & 3);
         const int cnt = __builtin_amdgcn_readfirstlane(desc[2]) - begin;       // items of this wave (may be <= 0)
         if (cnt <= 0) continue;
         const int ch = bucket >> 9, blk = bucket & 511;
-        const int rows = __builtin_amdgcn_readfirstlane(dict.block_rows[blk]);
-        const int my_tc = ws.items[begin + (slot < cnt ? slot : 0)];
+        const int my_tc = da.items[begin + (slot < cnt ? slot : 0)];
+        // the block's four f32 tiles: issued before anything waits, consumed after the residuals are staged
+        const float4* tiles = (const float4*)(da.detail_f32 + ((long long)ch * da.num_base + blk) * kBlockFilterTiles * 1024);
+        float4 av[kBlockFilterTiles][4];
+#pragma unroll
+        for (int tile = 0; tile < kBlockFilterTiles; ++tile)
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq) av[tile][kq] = tiles[(tile * 4 + kq) * 64 + lane];
+        const int rows = __builtin_amdgcn_readfirstlane(da.block_rows[blk]);
+        double rv[kFilterGroup];
+#pragma unroll
+        for (int i = 0; i < kFilterGroup; ++i) rv[i] = da.r[(long long)__builtin_amdgcn_readlane(my_tc, i) * N + lane];
         bool nz = false;
-#pragma unroll 4
+#pragma unroll
         for (int i = 0; i < kFilterGroup; ++i) {
-            const int tci = __builtin_amdgcn_readlane(my_tc, i);
-            const double v = ws.r[(long long)tci * N + lane];
-            s_r[i * kStageStride + lane] = v;
-            const bool any = __ballot(v != 0.0) != 0;
+            s_r[i * kStageStride + lane] = rv[i];
+            const bool any = __ballot(rv[i] != 0.0) != 0;
             if (slot == i) nz = any;
         }
         __syncthreads();
         float rb[16];
         const double ss = load_b_operand(rb, s_r, lane);
         const float window = 2.0f * (kFilterSlack * (float)__builtin_sqrt(ss) + kFilterAbs);
-        const float4* tiles = (const float4*)(dict.detail_f32 + ((long long)ch * dict.num_base + blk) * kBlockFilterTiles * 1024);
 #pragma unroll
         for (int tile = 0; tile < kBlockFilterTiles; ++tile) {
-            const f32x4 acc = mfma_tile(tiles + tile * 256, rb, lane);
+            f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tile][kq].x, rb[4 * kq + 0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tile][kq].y, rb[4 * kq + 1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tile][kq].z, rb[4 * kq + 2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tile][kq].w, rb[4 * kq + 3], acc, 0, 0, 0);
+            }
 #pragma unroll
             for (int v = 0; v < 4; ++v) s_p[(tile * 16 + sub * 4 + v) * kFilterGroup + slot] = acc[v];
         }
@@ -621,28 +800,24 @@ __global__ __launch_bounds__(64, 4) void mp_detail_filter_kernel(const Workspace
         }
         mx = fmaxf(mx, __shfl_xor(mx, 16));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float thr = mx - window;
+        const float thr = fmaxf(mx, da.approx_max[my_tc]) - window;      // a row far below the base maximum cannot win
+        __syncthreads();                                         // s_p is dead from here: its space takes the products
         unsigned mask = 0;
         if (slot < cnt && nz) {
 #pragma unroll
             for (int i = 0; i < 16; ++i)
-                if (!(pv[i] < thr) && 4 * i + sub < rows) mask |= 1u << i;
+                if (!(pv[i] < thr)) mask |= 1u << i;
+            mask &= low_bits((rows - sub + 3) >> 2);
         }
-        double best_val = 0.0;
-        int best_row = -1;
-        const double* block = dict.detail + ((long long)ch * dict.detail_rows + __builtin_amdgcn_readfirstlane(dict.block_row_off[blk])) * N;
-        while (mask) {
-            const int i = __builtin_ctz(mask);
-            mask &= mask - 1;
-            const int a = 4 * i + sub;
-            const double p = dot_exact(block + (long long)a * N, s_r + slot * kStageStride);
-            if (__builtin_fabs(p) > __builtin_fabs(best_val)) { best_val = p; best_row = a; }
-        }
+        double best_val, unused_val;
+        int best_row, unused_row;
+        const double* block = da.detail + ((long long)ch * da.detail_rows + __builtin_amdgcn_readfirstlane(da.block_row_off[blk])) * N;
+        evaluate_survivors(s_cand, s_r, lane, mask, 0u, 0, 0, block, block, best_val, best_row, unused_val, unused_row);
         keep_better(best_val, best_row, __shfl_xor(best_val, 16), __shfl_xor(best_row, 16));
         keep_better(best_val, best_row, __shfl_xor(best_val, 32), __shfl_xor(best_row, 32));
         if (sub == 0 && slot < cnt) {
-            ws.cand_val[(long long)(begin + slot) * kMaxRowParts] = best_val;
-            ws.cand_row[(long long)(begin + slot) * kMaxRowParts] = best_row;
+            da.cand_val[(long long)(begin + slot) * kMaxRowParts] = best_val;
+            da.cand_row[(long long)(begin + slot) * kMaxRowParts] = best_row;
         }
         __syncthreads();
     }
@@ -719,7 +894,7 @@ __global__ __launch_bounds__(256) void mp_fill_kernel(const Workspace ws, int cu
         int tc = 0, nb = 0;
         if (valid) {
             tc = ws.act[cur][ch][pos];
-            nb = ws.nblk[tc];
+            nb = nblk_count(ws.nblk[tc]);
             for (int i = 0; i < nb; ++i) {
                 const unsigned e = ws.blk_list[(long long)tc * kMaxDeviceK + i];
                 if (!entry_is_item(e)) continue;
@@ -774,7 +949,8 @@ __global__ __launch_bounds__(256) void mp_finish_kernel(const Workspace ws, cons
     const int tc = ws.act[cur][ch][pos];
     const unsigned oi = (unsigned)ws.out_index[tc];
     const long long rec = (long long)(oi & 0x3FFFFFFFu);
-    const int nb = ws.nblk[tc];
+    const int nblk_word = ws.nblk[tc];
+    const int nb = nblk_count(nblk_word);
     const int extra = ws.extra_rows[tc];
 
     double best_val = 0.0;
@@ -840,7 +1016,7 @@ __global__ __launch_bounds__(256) void mp_finish_kernel(const Workspace ws, cons
                 for (int i = 0; i < nb; ++i)
                     if (entry_block(ws.blk_list[(long long)tc * kMaxDeviceK + i]) == best_idx) e |= 0x8000u;
                 ws.blk_list[(long long)tc * kMaxDeviceK + nb] = (uint16_t)e;
-                ws.nblk[tc] = nb + 1;
+                ws.nblk[tc] = (nb + 1) | (nblk_word & 0x100) | (best_idx == 0 ? 0x100 : 0);
                 ws.extra_rows[tc] = extra + new_rows;
                 unlocked = true;
             }
@@ -1107,6 +1283,7 @@ Workspace carve(char* mem, int cap, int K, size_t* total)
         for (int ch = 0; ch < 3; ++ch) w.act[a][ch] = c.take<int>(n);
     w.cand0_val = c.take<double>(n);
     w.cand0_row = c.take<int>(n);
+    w.approx_max = c.take<float>(n);
     w.upd_coeff = c.take<double>(n);
     w.upd_sel = c.take<int>(n);
     w.counters = c.take<unsigned>(16);
@@ -1132,10 +1309,50 @@ size_t workspace_bytes(int cap, int K)
 
 Workspace carve_workspace(void* device_mem, int cap, int K) { return carve(static_cast<char*>(device_mem), cap, K, nullptr); }
 
+namespace {
+FilterArgs filter_args(const Workspace& ws, const DictDevice& dict, int cur)
+{
+    FilterArgs fa{};
+    fa.counters_in = ws.counters;
+    fa.counters_out = ws.counters;
+    for (int ch = 0; ch < 3; ++ch) {
+        fa.act[ch] = ws.act[cur][ch];
+        fa.block0[ch] = dict.detail + (long long)ch * dict.detail_rows * N;
+        fa.block0_f32[ch] = dict.detail_f32 + (long long)ch * dict.num_base * kBlockFilterTiles * 1024;
+    }
+    fa.r = ws.r;
+    fa.nblk = ws.nblk;
+    fa.part_val = ws.part_val;
+    fa.part_idx = ws.part_idx;
+    fa.cand0_val = ws.cand0_val;
+    fa.cand0_row = ws.cand0_row;
+    fa.approx_max = ws.approx_max;
+    fa.base = dict.base;
+    fa.base_f32 = dict.base_f32;
+    fa.num_base = dict.num_base;
+    fa.rows0 = dict.block0_rows;
+    return fa;
+}
+}  // namespace
+
 int enqueue_pursuit(const DictDevice& dict, const Workspace& ws, const FrameInput& in, const Outputs& out,
                     const double* quant_dev, int K, long long tc_begin, int n, int parts, int row_parts, int sweep_waves,
                     void* stream_, void** base_events, void* side_stream_, void* fork_event_, void* join_event_)
 {
+    DetailFilterArgs detail_args{};
+    detail_args.counters = ws.counters;
+    detail_args.chunks = ws.chunks;
+    detail_args.items = ws.items;
+    detail_args.r = ws.r;
+    detail_args.cand_val = ws.cand_val;
+    detail_args.cand_row = ws.cand_row;
+    detail_args.approx_max = ws.approx_max;
+    detail_args.detail = dict.detail;
+    detail_args.detail_rows = dict.detail_rows;
+    detail_args.detail_f32 = dict.detail_f32;
+    detail_args.block_rows = dict.block_rows;
+    detail_args.block_row_off = dict.block_row_off;
+    detail_args.num_base = dict.num_base;
     hipStream_t s = static_cast<hipStream_t>(stream_);
     hipStream_t side = static_cast<hipStream_t>(side_stream_);
     hipEvent_t ev_fork = static_cast<hipEvent_t>(fork_event_), ev_join = static_cast<hipEvent_t>(join_event_);
@@ -1175,8 +1392,8 @@ int enqueue_pursuit(const DictDevice& dict, const Workspace& ws, const FrameInpu
         }
         if (base_events) (void)hipEventRecord(static_cast<hipEvent_t>(base_events[2 * step]), s);
         if (filtered)
-            hipLaunchKernelGGL(mp_filter_kernel, dim3(clampu(lists * (unsigned)((per_list + 15) / 16), 768u)), dim3(256), 0, s, ws,
-                               dict, cur, step > 0 ? 1 : 0);
+            hipLaunchKernelGGL(mp_filter_kernel, dim3(clampu(lists * (unsigned)((per_list + 15) / 16), 768u)), dim3(256), 0, s,
+                               filter_args(ws, dict, cur), cur, step > 0 ? 1 : 0);
         else
             hipLaunchKernelGGL(mp_base_kernel, dim3(clampu(max_groups * (unsigned)(parts + 1), slots)), dim3(64), 0, s, ws, dict,
                                cur, parts, step > 0 ? 1 : 0, (int)slots);
@@ -1186,7 +1403,7 @@ int enqueue_pursuit(const DictDevice& dict, const Workspace& ws, const FrameInpu
                 (void)hipEventRecord(ev_join, side);
                 (void)hipStreamWaitEvent(s, ev_join, 0);
             } else if (filtered) {
-                hipLaunchKernelGGL(mp_detail_filter_kernel, dim3(clampu(max_groups * 4u, 3072u)), dim3(64), 0, s, ws, dict);
+                hipLaunchKernelGGL(mp_detail_filter_kernel, dim3(clampu(max_groups * 4u, 3072u)), dim3(64), 0, s, detail_args);
             } else {
                 hipLaunchKernelGGL(mp_detail_kernel, dim3(clampu(max_groups * (unsigned)row_parts, slots)), dim3(64), 0, s, ws,
                                    dict, row_parts, (int)slots, ws.cand_val);

@@ -108,6 +108,7 @@ mpc::DictDevice dict_device(const mpc_context* c) {
     d.detail = c->d_detail;
     d.detail_rows = c->dict.total_detail_rows();
     d.block_rows = c->d_rows;
+    d.block0_rows = c->dict.block_rows.empty() ? 0 : c->dict.block_rows[0];
     d.block_row_off = c->d_rowoff;
     d.base_f32 = c->d_base_f32;
     d.detail_f32 = c->d_detail_f32;
