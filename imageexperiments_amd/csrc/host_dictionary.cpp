@@ -506,7 +506,14 @@ std::vector<double> base_padded(const Dictionary& d, int pad_rows, int* padded_r
     return out;
 }
 
-std::vector<float> filter_tiles(const double* rows, int nrows, int tiles) {
+uint16_t bf16_round(float x) {
+    uint32_t bits;
+    std::memcpy(&bits, &x, sizeof(bits));
+    bits += 0x7FFFu + ((bits >> 16) & 1u);
+    return static_cast<uint16_t>(bits >> 16);
+}
+
+std::vector<uint16_t> filter_tiles(const double* rows, int nrows, int tiles) {
     std::vector<char> shadowed(static_cast<size_t>(nrows), 0);
     for (int j = 1; j < nrows; ++j)
         for (int i = 0; i < j && !shadowed[j]; ++i) {
@@ -519,16 +526,22 @@ std::vector<float> filter_tiles(const double* rows, int nrows, int tiles) {
             }
             if (same || negated) shadowed[j] = 1;
         }
-    std::vector<float> out(static_cast<size_t>(tiles) * kFilterTileFloats, 0.0f);
+    std::vector<uint16_t> out(static_cast<size_t>(tiles) * kFilterTileHalves, 0);
     for (int tile = 0; tile < tiles; ++tile)
-        for (int kq = 0; kq < 4; ++kq)
+        for (int kk = 0; kk < 2; ++kk)
             for (int lane = 0; lane < 64; ++lane)
-                for (int e = 0; e < 4; ++e) {
+                for (int j = 0; j < 8; ++j) {
                     const int row = tile * 16 + (lane & 15);
-                    const int k = 4 * (4 * kq + e) + (lane >> 4);
-                    if (row < nrows && !shadowed[row])
-                        out[((static_cast<size_t>(tile) * 4 + kq) * 64 + lane) * 4 + e] =
-                            static_cast<float>(rows[static_cast<size_t>(row) * kTileN + k]);
+                    const int k = 32 * kk + 8 * (lane >> 4) + j;
+                    if (row >= nrows || shadowed[row]) continue;
+                    const float x = static_cast<float>(rows[static_cast<size_t>(row) * kTileN + k]);
+                    const uint16_t hi = bf16_round(x);
+                    const uint32_t hi_bits = static_cast<uint32_t>(hi) << 16;
+                    float hi_f;
+                    std::memcpy(&hi_f, &hi_bits, sizeof(hi_f));
+                    const uint16_t lo = bf16_round(x - hi_f);
+                    out[((static_cast<size_t>(tile) * 4 + 2 * kk + 0) * 64 + lane) * 8 + j] = hi;
+                    out[((static_cast<size_t>(tile) * 4 + 2 * kk + 1) * 64 + lane) * 8 + j] = lo;
                 }
     return out;
 }

@@ -55,13 +55,15 @@ void quantisation_tables(int K, int block_size, double bpp, double* quant);
 // Select starts from bestCoeff = 0 with a strict '>', MatchingPursuit.cpp:9-19).
 std::vector<double> base_padded(const Dictionary& d, int pad_rows, int* padded_rows);
 
-// Single-precision copy of `nrows` dictionary rows (row-major doubles, n = 64) for the device's filter pass,
-// padded with zero rows to `tiles` tiles of 16 rows and laid out in the operand order of v_mfma_f32_16x16x4_f32:
-//   out[((tile*4 + kq)*64 + lane)*4 + e] = (float) rows[tile*16 + (lane & 15)][4*(4*kq + e) + (lane >> 4)]
-// so that one 16-byte load per lane feeds four consecutive MFMAs.  4 KiB per tile.
+// Reduced-precision copy of `nrows` dictionary rows (row-major doubles, n = 64) for the device's filter pass: every
+// element x is split into two bfloat16 values hi = bf16(x), lo = bf16(x - hi) (x = hi + lo to 2^-16 relative), the rows
+// are padded with zero rows to `tiles` tiles of 16 and laid out in the operand order of v_mfma_f32_16x16x32_bf16:
+//   out[((tile*4 + 2*kk + part)*64 + lane)*8 + j] = part(rows[tile*16 + (lane & 15)][32*kk + 8*(lane >> 4) + j])
+// (part 0 = hi, 1 = lo; kk = 0, 1), so that one 16-byte load per lane is one MFMA operand.  4 KiB per tile.
 // A row that is bit-for-bit +-(an earlier row) is left zero: its projection ties with the earlier row's exactly
 // (IEEE negation commutes with every rounding of the dot product), so Select()'s strict '>' never returns it.
-std::vector<float> filter_tiles(const double* rows, int nrows, int tiles);
-constexpr int kFilterTileFloats = 1024;
+std::vector<uint16_t> filter_tiles(const double* rows, int nrows, int tiles);
+constexpr int kFilterTileHalves = 2048;       // 16-bit elements per tile
+uint16_t bf16_round(float x);                 // round to nearest even
 
 }  // namespace mpc

@@ -31,7 +31,7 @@ constexpr int kMaxDeviceK = 32;
 constexpr int kMaxParts = 8;            // base sweep can be split over up to 8 atom ranges per tile-channel group
 constexpr int kChunkItems = 64;         // items (tile-channels) a wave processes per loaded detail block
 constexpr int kNumBuckets = 3 * 512;    // (channel, block) buckets, block < 510
-constexpr int kBaseFilterTiles = 32;    // 16-row tiles of the f32 filter copy of the base dictionary (512 rows)
+constexpr int kBaseFilterTiles = 32;    // 16-row tiles of the filter copy of the base dictionary (512 rows)
 constexpr int kBlockFilterTiles = 4;    // ... of one detail block (62 | 63 rows, padded to 64)
 constexpr int kMaxRowParts = 4;         // a detail block's 62/63 rows can be split over up to 4 waves
 
@@ -44,9 +44,9 @@ struct DictDevice {
     const int32_t* block_rows;       // [num_base]
     int block0_rows;                 // block_rows[0] (host copy)
     const int32_t* block_row_off;    // [num_base+1]
-    // single-precision copies for the filter pass, in MFMA operand order (host_dictionary.h: filter_tiles)
-    const float* base_f32;           // [kBaseFilterTiles][1024]: base rows 0..511 (510 + 2 zero rows)
-    const float* detail_f32;         // [3][num_base][kBlockFilterTiles][1024]: every detail block padded to 64 rows
+    // split-bfloat16 copies for the filter pass, in MFMA operand order (host_dictionary.h: filter_tiles), 2048 halves per tile
+    const uint16_t* base_f32;        // [kBaseFilterTiles][2048]: base rows 0..511 (510 + 2 zero rows)
+    const uint16_t* detail_f32;      // [3][num_base][kBlockFilterTiles][2048]: every detail block padded to 64 rows
 };
 
 // Per-batch device workspace (all device pointers). cap = max tile-channels per batch.

@@ -285,15 +285,18 @@ __global__ __launch_bounds__(64, 3) void mp_base_kernel(const Workspace ws, cons
 
 // --------------------------------------------------------------------------------------------------
 // filtered sweeps.  The argmax of Select() only needs the exact projection of the rows that can be the
-// maximum.  So: (1) approximate ALL projections of a group of 16 tile-channels in single precision on the matrix
+// maximum.  So: (1) approximate ALL projections of a group of 16 tile-channels in split bfloat16 on the matrix
 // cores, (2) keep, per tile-channel, the rows whose approximation is within 2E of the largest one, (3) evaluate
 // only those in the reference's arithmetic (sequential double dot product, mathmatrix.cpp:436-444) and pick the
 // first strict maximum among them in row order.  The result is bit-identical to sweeping every row:
-//   * v_mfma_f32_16x16x4_f32 is an f32 fma chain in k order, so with u = 2^-24 its value differs from the real
-//     dot product by at most ((1+u)^66 - 1) * sum|r_j b_j| <= 66.01 u |r|_2 |b|_2 (operand roundings included),
-//     plus < 2^-142 where products fall into the f32 subnormal range; the reference's double value differs from
-//     the real one by < 2^-46 of that.  Rows have |b|_2 <= 1 + 2^-50.  E = 2^-17 |r~|_2 + 2^-140 (128 u |r~|_2, r~ the
-//     f32-rounded residual) leaves a factor ~1.9 over all of it.
+//   * the approximation is a split-bfloat16 product on v_mfma_f32_16x16x32_bf16: residual and row elements are
+//     x = hi + lo + e, hi = bf16(x), lo = bf16(x - hi), |e| <= 2^-16 |x| (u = 2^-8 per rounding), and the three MFMAs
+//     hi*hi + hi*lo + lo*hi leave out lo*lo <= 2^-16 |r_j b_j|: at most 3 * 2^-16 * sum|r_j b_j| in all.  The products
+//     of two 8-bit significands are exact in f32; accumulating 6 x 32 of them in f32 (any order, any rounding mode)
+//     adds at most 6 * 33 * 2^-23 of sum|r_j b_j|.  With sum|r_j b_j| <= |r|_2 |b|_2 and |b|_2 <= 1 + 2^-50 that is
+//     < 7.0e-5 |r|_2, plus < 2^-110 where operands or products are subnormal; the reference's double value differs
+//     from the real dot product by < 2^-46 |r|_2.  E = 2^-13 |r~|_2 + 2^-100 (r~ = the f32-rounded residual) leaves a
+//     factor ~1.7 over all of it.
 //   * let j* be the row Select() returns (lowest index with maximal exact |p|) and j~ the approximate maximum:
 //     approx|p_j*| >= |p_j*| - E >= |p_j~| - E >= approx|p_j~| - 2E, so j* is kept -- as is every row tying with it.
 //   * overflow / NaN anywhere makes the comparison `approx < threshold` false: the row is kept and evaluated.
@@ -301,7 +304,7 @@ __global__ __launch_bounds__(64, 3) void mp_base_kernel(const Workspace ws, cons
 //     a smaller maximum only lowers it.  Base rows and block 0 share one (mp_filter_kernel), which it also leaves in
 //     approx_max[] for the detail blocks (mp_detail_filter_kernel): a block whose best row is far below the base
 //     maximum yields no survivor at all and reports "none" (index -1), which the finish kernel skips.
-//   * rows that are +-copies of an earlier row (base row 509 = -row 0) are zero in the f32 copy: they tie with the
+//   * rows that are +-copies of an earlier row (base row 509 = -row 0) are zero in the filter copy: they tie with the
 //     earlier row exactly and can never be returned (host_dictionary.cpp: filter_tiles).
 // --------------------------------------------------------------------------------------------------
 namespace {
@@ -311,23 +314,54 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kFilterGroup = 16;                                          // tile-channels per MFMA column block
 constexpr int kFilterRows = 16 * (kBaseFilterTiles + kBlockFilterTiles);  // 576 = 512 base + 64 of block 0
 constexpr int kStageStride = N + 1;                                       // doubles per staged residual (+1: bank spread)
-constexpr float kFilterSlack = 0x1p-17f;
-constexpr float kFilterAbs = 0x1p-140f;
+constexpr float kFilterSlack = 0x1p-13f;
+constexpr float kFilterAbs = 0x1p-100f;
 
-// B operand of the 16x16x4 MFMAs for 16 staged residuals: lane (slot = l & 15, kg = l >> 4) holds r~[slot][4kk + kg];
-// also returns |r~[slot]|^2 (summed over the four kg lanes)
-__device__ __forceinline__ double load_b_operand(float (&rb)[16], const double* stage, int lane)
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned bf16_bits(float x)       // round to nearest even, like host_dictionary.cpp: bf16_round
 {
-    const double* src = stage + (lane & 15) * kStageStride + (lane >> 4);
+    const unsigned bits = __float_as_uint(x);
+    return (bits + 0x7FFFu + ((bits >> 16) & 1u)) >> 16;
+}
+
+// B operand of the 16x16x32 MFMAs for 16 staged residuals: lane (slot = l & 15, h = l >> 4) holds, for kk = 0, 1, the
+// eight elements r~[slot][32kk + 8h + j] split into hi[kk] and lo[kk]; also returns |r~[slot]|^2 (summed over the
+// four h lanes)
+__device__ __forceinline__ double load_b_operand(bf16x8 (&hi)[2], bf16x8 (&lo)[2], const double* stage, int lane)
+{
+    const double* src = stage + (lane & 15) * kStageStride + 8 * (lane >> 4);
     double ss = 0.0;
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
-        rb[kk] = (float)src[4 * kk];
-        ss += (double)rb[kk] * (double)rb[kk];
-    }
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float x = (float)src[32 * kk + j];
+            ss += (double)x * (double)x;
+            const unsigned h = bf16_bits(x);
+            const unsigned l = bf16_bits(x - __uint_as_float(h << 16));
+            hi[kk][j] = (short)h;
+            lo[kk][j] = (short)l;
+        }
     ss += __shfl_xor(ss, 16);
     ss += __shfl_xor(ss, 32);
     return ss;
+}
+
+// one 16-row tile of the filter copy (four 16-byte operands per lane: hi/lo x two k halves) against the B operand
+__device__ __forceinline__ f32x4 filter_tile_mfma(const uint4 (&a)[4], const bf16x8 (&hi)[2], const bf16x8 (&lo)[2])
+{
+    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        bf16x8 ah, al;
+        __builtin_memcpy(&ah, &a[2 * kk + 0], 16);
+        __builtin_memcpy(&al, &a[2 * kk + 1], 16);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, hi[kk], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, lo[kk], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, hi[kk], acc, 0, 0, 0);
+    }
+    return acc;
 }
 
 // mask of the lowest n bits (n may be <= 0 or >= 32)
@@ -436,8 +470,8 @@ struct FilterArgs {
     float* approx_max;               // out: largest approximation over base + block 0, per tile-channel
     const double* base;              // dictionary, double
     const double* block0[3];         // DetailBasis[0] of each channel, double
-    const float* base_f32;           // filter copies
-    const float* block0_f32[3];
+    const uint16_t* base_f32;        // filter copies
+    const uint16_t* block0_f32[3];
     int num_base, rows0;
 };
 
@@ -451,7 +485,7 @@ struct DetailFilterArgs {
     const float* approx_max;         // written by mp_filter_kernel earlier in the step
     const double* detail;            // [3][detail_rows][64]
     long long detail_rows;
-    const float* detail_f32;
+    const uint16_t* detail_f32;
     const int32_t* block_rows;
     const int32_t* block_row_off;
     int num_base;
@@ -545,21 +579,21 @@ __global__ __launch_bounds__(256, MPC_FILTER_OCC) void mp_filter_kernel(const Fi
         // ---- (1) approximate projections; wave w takes tiles w, w+4, ...
         float window;
         {
-            float rb[16];
-            const double ss = load_b_operand(rb, s_r, lane);
+            bf16x8 r_hi[2], r_lo[2];
+            const double ss = load_b_operand(r_hi, r_lo, s_r, lane);
             window = 2.0f * (kFilterSlack * (float)__builtin_sqrt(ss) + kFilterAbs);
-            const float* tiles0 = ch == 0 ? fa.block0_f32[0] : (ch == 1 ? fa.block0_f32[1] : fa.block0_f32[2]);
+            const uint16_t* tiles0 = ch == 0 ? fa.block0_f32[0] : (ch == 1 ? fa.block0_f32[1] : fa.block0_f32[2]);
             auto tile_ptr = [&](int tile) {
-                return (const float4*)(tile < kBaseFilterTiles ? fa.base_f32 + tile * 1024 : tiles0 + (tile - kBaseFilterTiles) * 1024);
+                return (const uint4*)(tile < kBaseFilterTiles ? fa.base_f32 + tile * 2048 : tiles0 + (tile - kBaseFilterTiles) * 2048);
             };
             // nine (eight at step 0) tiles per wave, kAhead tile reads (4 x 16 B per lane each) in flight ahead of the MFMAs
             constexpr int kPerWave = (kBaseFilterTiles + kBlockFilterTiles) / 4, kAhead = MPC_FILTER_AHEAD;
-            float4 av[kAhead][4];
+            uint4 av[kAhead][4];
 #pragma unroll
             for (int i = 0; i < kAhead; ++i) {
-                const float4* a = tile_ptr(wave + 4 * i);
+                const uint4* a = tile_ptr(wave + 4 * i);
 #pragma unroll
-                for (int kq = 0; kq < 4; ++kq) av[i][kq] = a[kq * 64 + lane];
+                for (int q = 0; q < 4; ++q) av[i][q] = a[q * 64 + lane];
             }
 #pragma unroll
             for (int i = 0; i < kPerWave; ++i) {
@@ -567,18 +601,11 @@ __global__ __launch_bounds__(256, MPC_FILTER_OCC) void mp_filter_kernel(const Fi
                 if (i == 2) { MPC_FETCH_IDS(u + (int)gridDim.x) }
                 if (i == 6) { MPC_FETCH_ROWS(u + (int)gridDim.x) }
                 if (tile < ntiles) {
-                    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-                    for (int kq = 0; kq < 4; ++kq) {
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i % kAhead][kq].x, rb[4 * kq + 0], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i % kAhead][kq].y, rb[4 * kq + 1], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i % kAhead][kq].z, rb[4 * kq + 2], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i % kAhead][kq].w, rb[4 * kq + 3], acc, 0, 0, 0);
-                    }
+                    const f32x4 acc = filter_tile_mfma(av[i % kAhead], r_hi, r_lo);
                     if (i + kAhead < kPerWave && tile + 4 * kAhead < ntiles) {
-                        const float4* a = tile_ptr(tile + 4 * kAhead);
+                        const uint4* a = tile_ptr(tile + 4 * kAhead);
 #pragma unroll
-                        for (int kq = 0; kq < 4; ++kq) av[i % kAhead][kq] = a[kq * 64 + lane];
+                        for (int q = 0; q < 4; ++q) av[i % kAhead][q] = a[q * 64 + lane];
                     }
 #pragma unroll
                     for (int v = 0; v < 4; ++v) s_p[(tile * 16 + sub * 4 + v) * kFilterGroup + slot] = acc[v];
@@ -735,8 +762,8 @@ __global__ __launch_bounds__(64, 3) void mp_detail_kernel(const Workspace ws, co
 }
 
 // filtered detail sweep: the same filter for the bucketed detail blocks.  One wave per 16 items of a chunk
-// (<= 64 items of one (channel, block) bucket): 64 x 16 approximations (4 tiles, 64 MFMAs), then lane (slot, sub)
-// scans every fourth row of its item and the survivors are evaluated exactly.  12 KiB of LDS per wave.
+// (<= 64 items of one (channel, block) bucket): 64 x 16 approximations (4 tiles, 24 MFMAs), then lane (slot, sub)
+// scans every fourth row of its item and the survivors are evaluated exactly.  16 KiB of LDS per wave.
 __global__ __launch_bounds__(64) void mp_detail_filter_kernel(const DetailFilterArgs da)
 {
     __shared__ __attribute__((aligned(16))) char s_buf[sizeof(CandLds)];   // approximations [row][slot], then the products
@@ -755,13 +782,13 @@ __global__ __launch_bounds__(64) void mp_detail_filter_kernel(const DetailFilter
         if (cnt <= 0) continue;
         const int ch = bucket >> 9, blk = bucket & 511;
         const int my_tc = da.items[begin + (slot < cnt ? slot : 0)];
-        // the block's four f32 tiles: issued before anything waits, consumed after the residuals are staged
-        const float4* tiles = (const float4*)(da.detail_f32 + ((long long)ch * da.num_base + blk) * kBlockFilterTiles * 1024);
-        float4 av[kBlockFilterTiles][4];
+        // the block's four filter tiles: issued before anything waits, consumed after the residuals are staged
+        const uint4* tiles = (const uint4*)(da.detail_f32 + ((long long)ch * da.num_base + blk) * kBlockFilterTiles * 2048);
+        uint4 av[kBlockFilterTiles][4];
 #pragma unroll
         for (int tile = 0; tile < kBlockFilterTiles; ++tile)
 #pragma unroll
-            for (int kq = 0; kq < 4; ++kq) av[tile][kq] = tiles[(tile * 4 + kq) * 64 + lane];
+            for (int q = 0; q < 4; ++q) av[tile][q] = tiles[(tile * 4 + q) * 64 + lane];
         const int rows = __builtin_amdgcn_readfirstlane(da.block_rows[blk]);
         double rv[kFilterGroup];
 #pragma unroll
@@ -774,19 +801,12 @@ __global__ __launch_bounds__(64) void mp_detail_filter_kernel(const DetailFilter
             if (slot == i) nz = any;
         }
         __syncthreads();
-        float rb[16];
-        const double ss = load_b_operand(rb, s_r, lane);
+        bf16x8 r_hi[2], r_lo[2];
+        const double ss = load_b_operand(r_hi, r_lo, s_r, lane);
         const float window = 2.0f * (kFilterSlack * (float)__builtin_sqrt(ss) + kFilterAbs);
 #pragma unroll
         for (int tile = 0; tile < kBlockFilterTiles; ++tile) {
-            f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-            for (int kq = 0; kq < 4; ++kq) {
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tile][kq].x, rb[4 * kq + 0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tile][kq].y, rb[4 * kq + 1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tile][kq].z, rb[4 * kq + 2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tile][kq].w, rb[4 * kq + 3], acc, 0, 0, 0);
-            }
+            const f32x4 acc = filter_tile_mfma(av[tile], r_hi, r_lo);
 #pragma unroll
             for (int v = 0; v < 4; ++v) s_p[(tile * 16 + sub * 4 + v) * kFilterGroup + slot] = acc[v];
         }
@@ -1318,7 +1338,7 @@ FilterArgs filter_args(const Workspace& ws, const DictDevice& dict, int cur)
     for (int ch = 0; ch < 3; ++ch) {
         fa.act[ch] = ws.act[cur][ch];
         fa.block0[ch] = dict.detail + (long long)ch * dict.detail_rows * N;
-        fa.block0_f32[ch] = dict.detail_f32 + (long long)ch * dict.num_base * kBlockFilterTiles * 1024;
+        fa.block0_f32[ch] = dict.detail_f32 + (long long)ch * dict.num_base * kBlockFilterTiles * 2048;
     }
     fa.r = ws.r;
     fa.nblk = ws.nblk;

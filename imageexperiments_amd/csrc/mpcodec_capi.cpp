@@ -58,8 +58,8 @@ struct mpc_context {
     double* d_quant = nullptr;
     int32_t* d_rows = nullptr;
     int32_t* d_rowoff = nullptr;
-    float* d_base_f32 = nullptr;      // filter copies (mp_device.h)
-    float* d_detail_f32 = nullptr;
+    uint16_t* d_base_f32 = nullptr;   // filter copies (mp_device.h)
+    uint16_t* d_detail_f32 = nullptr;
     int* d_flag = nullptr;            // decode: set when a record indexes outside its dictionary
     // The pursuit of a call is cut into sub-batches that run on `pipes` internal streams, each with its own
     // workspace: the latency-bound bookkeeping kernels of one sub-batch (finish, update, bucket, fill) overlap
@@ -256,14 +256,14 @@ mpc_status mpc_context_create(int K, int block_size, double bpp, int device, mpc
         if (e == hipSuccess) e = upload(&c->d_quant, c->quant.data(), c->quant.size());
         if (e == hipSuccess) e = upload(&c->d_rows, c->dict.block_rows.data(), c->dict.block_rows.size());
         if (e == hipSuccess) e = upload(&c->d_rowoff, c->dict.block_row_off.data(), c->dict.block_row_off.size());
-        // single-precision copies for the filter pass: base rows as 16 tiles, every detail block as 2 tiles
+        // split-bfloat16 copies for the filter pass: base rows as 32 tiles of 16 rows, every detail block as 4
         {
-            const std::vector<float> base32 = mpc::filter_tiles(c->dict.base.data(), c->dict.num_base, mpc::kBaseFilterTiles);
-            std::vector<float> det32;
-            det32.reserve(3 * static_cast<size_t>(c->dict.num_base) * mpc::kBlockFilterTiles * mpc::kFilterTileFloats);
+            const std::vector<uint16_t> base32 = mpc::filter_tiles(c->dict.base.data(), c->dict.num_base, mpc::kBaseFilterTiles);
+            std::vector<uint16_t> det32;
+            det32.reserve(3 * static_cast<size_t>(c->dict.num_base) * mpc::kBlockFilterTiles * mpc::kFilterTileHalves);
             for (int ch = 0; ch < 3; ++ch)
                 for (int b = 0; b < c->dict.num_base; ++b) {
-                    const std::vector<float> t = mpc::filter_tiles(
+                    const std::vector<uint16_t> t = mpc::filter_tiles(
                         c->dict.detail[ch].data() + static_cast<size_t>(c->dict.block_row_off[b]) * mpc::kTileN,
                         c->dict.block_rows[b], mpc::kBlockFilterTiles);
                     det32.insert(det32.end(), t.begin(), t.end());

@@ -54,10 +54,10 @@ int main(int argc, char** argv)
     dd.block0_rows = dict.block_rows[0];
     dd.block_row_off = to_device(dict.block_row_off);
     dd.base_f32 = to_device(mpc::filter_tiles(dict.base.data(), dict.num_base, mpc::kBaseFilterTiles));
-    std::vector<float> det32;
+    std::vector<uint16_t> det32;
     for (int ch = 0; ch < 3; ++ch)
         for (int b = 0; b < dict.num_base; ++b) {
-            const std::vector<float> t = mpc::filter_tiles(dict.detail[ch].data() + static_cast<size_t>(dict.block_row_off[b]) * 64,
+            const std::vector<uint16_t> t = mpc::filter_tiles(dict.detail[ch].data() + static_cast<size_t>(dict.block_row_off[b]) * 64,
                                                            dict.block_rows[b], mpc::kBlockFilterTiles);
             det32.insert(det32.end(), t.begin(), t.end());
         }
