@@ -12,24 +12,12 @@
 // flight, issued right after the wait for the previous group, and relies on 2-3 co-resident waves per
 // SIMD to cover what 15 multiply-adds do not (measured: tools/ubench_scalar_sweep.hip).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <stdint.h>
 
 #include "mp_device.h"
 
 namespace mpc {
-
-// Phase stamps for tools/filter_probe.hip (-DMPC_STAMPS): shader clocks spent by thread 0 of each block between
-// consecutive MPC_STAMP points, summed over blocks.  Compiled out of the product library.
-#ifdef MPC_STAMPS
-__device__ unsigned long long g_stamps[16];
-#define MPC_STAMP_BEGIN() unsigned long long stamp_acc_[12] = {0}; unsigned long long stamp_last_ = __builtin_readcyclecounter();
-#define MPC_STAMP(k) { const unsigned long long now_ = __builtin_readcyclecounter(); stamp_acc_[k] += now_ - stamp_last_; stamp_last_ = now_; }
-#define MPC_STAMP_END() if (threadIdx.x == 0) { for (int k_ = 0; k_ < 12; ++k_) atomicAdd(&g_stamps[k_], stamp_acc_[k_]); }
-#else
-#define MPC_STAMP_BEGIN()
-#define MPC_STAMP(k)
-#define MPC_STAMP_END()
-#endif
 
 namespace {
 
@@ -301,7 +289,7 @@ __global__ __launch_bounds__(64, 3) void mp_base_kernel(const Workspace ws, cons
 //     approx|p_j*| >= |p_j*| - E >= |p_j~| - E >= approx|p_j~| - 2E, so j* is kept -- as is every row tying with it.
 //   * overflow / NaN anywhere makes the comparison `approx < threshold` false: the row is kept and evaluated.
 //   * the threshold may use the largest approximation over ANY subset of the rows the tile-channel can choose from:
-//     a smaller maximum only lowers it.  Base rows and block 0 share one (mp_filter_kernel), which it also leaves in
+//     a smaller maximum only lowers it.  Base rows and block 0 share one (mp_filter_wave_kernel), which it also leaves in
 //     approx_max[] for the detail blocks (mp_detail_filter_kernel): a block whose best row is far below the base
 //     maximum yields no survivor at all and reports "none" (index -1), which the finish kernel skips.
 //   * rows that are +-copies of an earlier row (base row 509 = -row 0) are zero in the filter copy: they tie with the
@@ -312,7 +300,6 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kFilterGroup = 16;                                          // tile-channels per MFMA column block
-constexpr int kFilterRows = 16 * (kBaseFilterTiles + kBlockFilterTiles);  // 576 = 512 base + 64 of block 0
 constexpr int kStageStride = N + 1;                                       // doubles per staged residual (+1: bank spread)
 constexpr float kFilterSlack = 0x1p-13f;
 constexpr float kFilterAbs = 0x1p-100f;
@@ -482,7 +469,7 @@ struct DetailFilterArgs {
     const double* r;
     double* cand_val;
     int* cand_row;
-    const float* approx_max;         // written by mp_filter_kernel earlier in the step
+    const float* approx_max;         // written by mp_filter_wave_kernel earlier in the step
     const double* detail;            // [3][detail_rows][64]
     long long detail_rows;
     const uint16_t* detail_f32;
@@ -491,210 +478,293 @@ struct DetailFilterArgs {
     int num_base;
 };
 
-// Base rows and (steps > 0) the 63 rows of DetailBasis[0], which the DC atom unlocks for nearly every tile-channel:
-// they ride along as four more tiles with their own threshold and their own result slot.
-// Block = 256 threads = 4 waves, 16 tile-channels of one channel's active list; 47 KiB of LDS, three blocks per CU.
-#ifndef MPC_FILTER_OCC
-#define MPC_FILTER_OCC 3
-#endif
-#ifndef MPC_FILTER_AHEAD
-#define MPC_FILTER_AHEAD 2
-#endif
-__global__ __launch_bounds__(256, MPC_FILTER_OCC) void mp_filter_kernel(const FilterArgs fa, int cur, int with_detail0)
+// --------------------------------------------------------------------------------------------------
+// Wave-autonomous filter kernels.  With the approximations on the bf16 matrix cores the MFMAs are cheap, and what
+// is left of a filtered sweep is memory latency and synchronisation.  So one WAVE takes up to 64 tile-channels (four
+// column groups of 16) and keeps everything in registers: the B operands are read straight from the residual rows,
+// pass 1 runs all row tiles through the MFMAs and only keeps each lane's running maximum, pass 2 runs them again and
+// compares against the threshold, queueing the few survivors for the cooperative exact evaluation.  No workgroup
+// barrier, no LDS besides the 8 KiB product buffer; each dictionary tile read serves up to 64 tile-channels.
+// --------------------------------------------------------------------------------------------------
+namespace {
+
+// B operand of one column group read from global memory: this lane's slot row, elements 32kk + 8h + j
+__device__ __forceinline__ double load_b_global(bf16x8 (&hi)[2], bf16x8 (&lo)[2], const double* row, int lane, bool& nonzero)
 {
-    __shared__ __attribute__((aligned(16))) float s_p[kFilterRows * kFilterGroup];   // approximate projections [row][slot]
-    static_assert(sizeof(float) * kFilterRows * kFilterGroup >= 4 * sizeof(CandLds), "product buffers overlay s_p");
-    __shared__ double s_r[kFilterGroup * kStageStride];      // the 16 residuals
-    __shared__ float s_max[2][4][kFilterGroup];              // [base | block 0][wave][slot]
-    __shared__ double s_val[2][4][kFilterGroup];
-    __shared__ int s_idx[2][4][kFilterGroup];
-    __shared__ int s_tc[kFilterGroup];
-    __shared__ int s_flags[kFilterGroup];                    // bit 0: residual has a non-zero element; bit 1: block 0 unlocked
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int slot = lane & 15, sub = lane >> 4;
-    if (blockIdx.x == 0 && t < 3) fa.counters_out[(cur ^ 1) * 3 + t] = 0;      // next step's active counts
-    const int n0 = (int)scalar_counter(fa.counters_in, cur * 3 + 0), n1 = (int)scalar_counter(fa.counters_in, cur * 3 + 1),
-              n2 = (int)scalar_counter(fa.counters_in, cur * 3 + 2);
-    const int g0 = (n0 + kFilterGroup - 1) / kFilterGroup, g1 = (n1 + kFilterGroup - 1) / kFilterGroup,
-              g2 = (n2 + kFilterGroup - 1) / kFilterGroup;
-    const int ntiles = kBaseFilterTiles + (with_detail0 ? kBlockFilterTiles : 0);
-    const int rows0 = fa.rows0;
-    const int total_units = g0 + g1 + g2;
-    const int* const act0 = fa.act[0];
-    const int* const act1 = fa.act[1];
-    const int* const act2 = fa.act[2];
-    // what a unit stages, fetched one unit ahead: residual element `lane` of the wave's four tile-channels.  In two
-    // stages (list entries, then what they point at), issued from inside the MFMA loop after the last tile read so
-    // that nothing later in program order has to wait for them (vector loads return in order).
-    double pre_v0 = 0.0, pre_v1 = 0.0, pre_v2 = 0.0, pre_v3 = 0.0;
-    int pre_id0 = 0, pre_id1 = 0, pre_id2 = 0, pre_id3 = 0;          // list entries (tile-channels), -1 past the end
-    int pre_nb0 = 0, pre_nb1 = 0, pre_nb2 = 0, pre_nb3 = 0;
-#define MPC_FETCH_IDS(unit_)                                                                                   \
-    if ((unit_) < total_units) {                                                                               \
-        const int c_ = __builtin_amdgcn_readfirstlane((unit_) < g0 ? 0 : ((unit_) < g0 + g1 ? 1 : 2));         \
-        const int first_ = ((unit_) - (c_ == 0 ? 0 : (c_ == 1 ? g0 : g0 + g1))) * kFilterGroup + wave * 4;     \
-        const int n_ = c_ == 0 ? n0 : (c_ == 1 ? n1 : n2);                                                     \
-        const int* list_ = c_ == 0 ? act0 : (c_ == 1 ? act1 : act2);                                           \
-        pre_id0 = first_ + 0 < n_ ? list_[first_ + 0] : -1;                                                    \
-        pre_id1 = first_ + 1 < n_ ? list_[first_ + 1] : -1;                                                    \
-        pre_id2 = first_ + 2 < n_ ? list_[first_ + 2] : -1;                                                    \
-        pre_id3 = first_ + 3 < n_ ? list_[first_ + 3] : -1;                                                    \
-    }
-#define MPC_FETCH_ROW(v_, nb_, id_)                                                                            \
-    v_ = (id_) >= 0 ? fa.r[(long long)(id_) * N + lane] : 0.0;                                                 \
-    nb_ = (id_) >= 0 ? fa.nblk[(id_)] : 0;
-#define MPC_FETCH_ROWS(unit_)                                                                                  \
-    if ((unit_) < total_units) {                                                                               \
-        MPC_FETCH_ROW(pre_v0, pre_nb0, pre_id0)                                                                \
-        MPC_FETCH_ROW(pre_v1, pre_nb1, pre_id1)                                                                \
-        MPC_FETCH_ROW(pre_v2, pre_nb2, pre_id2)                                                                \
-        MPC_FETCH_ROW(pre_v3, pre_nb3, pre_id3)                                                                \
-    }
-    MPC_FETCH_IDS((int)blockIdx.x)
-    MPC_FETCH_ROWS((int)blockIdx.x)
-    MPC_STAMP_BEGIN()
-    for (int u = blockIdx.x; u < total_units; u += gridDim.x) {
-        const int ch = __builtin_amdgcn_readfirstlane(u < g0 ? 0 : (u < g0 + g1 ? 1 : 2));
-
-        // ---- stage the 16 residuals: wave w brings rows 4w..4w+3, lane = pixel (one coalesced 512-byte read each);
-        //      they were fetched while the previous unit was being worked on
-#define MPC_STAGE(i_, v_, nb_, id_)                                                                            \
-        {                                                                                                      \
-            const int sl_ = wave * 4 + (i_);                                                                   \
-            s_r[sl_ * kStageStride + lane] = v_;                                                               \
-            const bool nz_ = __ballot(v_ != 0.0) != 0;                                                         \
-            if (lane == 0) {                                                                                   \
-                s_tc[sl_] = id_;                                                                               \
-                s_flags[sl_] = (nz_ ? 1 : 0) | ((with_detail0 && nblk_has0(nb_)) ? 2 : 0);                     \
-            }                                                                                                  \
+    const double2* src = (const double2*)(row + 8 * (lane >> 4));
+    double2 v[8];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int j2 = 0; j2 < 4; ++j2) v[4 * kk + j2] = src[16 * kk + j2];
+    double ss = 0.0;
+    bool nzl = false;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const double d = (j & 1) ? v[4 * kk + (j >> 1)].y : v[4 * kk + (j >> 1)].x;
+            nzl = nzl || (d != 0.0);
+            const float x = (float)d;
+            ss += (double)x * (double)x;
+            const unsigned h = bf16_bits(x);
+            const unsigned l = bf16_bits(x - __uint_as_float(h << 16));
+            hi[kk][j] = (short)h;
+            lo[kk][j] = (short)l;
         }
-        MPC_STAGE(0, pre_v0, pre_nb0, pre_id0)
-        MPC_STAGE(1, pre_v1, pre_nb1, pre_id1)
-        MPC_STAGE(2, pre_v2, pre_nb2, pre_id2)
-        MPC_STAGE(3, pre_v3, pre_nb3, pre_id3)
-        MPC_STAMP(0)
-        __syncthreads();
-        MPC_STAMP(1)
+    ss += __shfl_xor(ss, 16);
+    ss += __shfl_xor(ss, 32);
+    int nzi = nzl ? 1 : 0;
+    nzi |= __shfl_xor(nzi, 16);
+    nzi |= __shfl_xor(nzi, 32);
+    nonzero = nzi != 0;
+    return ss;
+}
 
-        // ---- (1) approximate projections; wave w takes tiles w, w+4, ...
-        float window;
-        {
-            bf16x8 r_hi[2], r_lo[2];
-            const double ss = load_b_operand(r_hi, r_lo, s_r, lane);
-            window = 2.0f * (kFilterSlack * (float)__builtin_sqrt(ss) + kFilterAbs);
-            const uint16_t* tiles0 = ch == 0 ? fa.block0_f32[0] : (ch == 1 ? fa.block0_f32[1] : fa.block0_f32[2]);
-            auto tile_ptr = [&](int tile) {
-                return (const uint4*)(tile < kBaseFilterTiles ? fa.base_f32 + tile * 2048 : tiles0 + (tile - kBaseFilterTiles) * 2048);
-            };
-            // nine (eight at step 0) tiles per wave, kAhead tile reads (4 x 16 B per lane each) in flight ahead of the MFMAs
-            constexpr int kPerWave = (kBaseFilterTiles + kBlockFilterTiles) / 4, kAhead = MPC_FILTER_AHEAD;
-            uint4 av[kAhead][4];
+__device__ __forceinline__ float max_abs4(const f32x4& a)
+{
+    return fmaxf(fmaxf(fabsf(a[0]), fabsf(a[1])), fmaxf(fabsf(a[2]), fabsf(a[3])));
+}
+
+// Per-lane FIFO of surviving rows waiting for their exact evaluation.  code = group << 12 | segment << 11 | row.
+struct SurvivorQueue {
+    int q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0;
+    int count = 0;
+    static constexpr int kCapacity = 6;
+    __device__ __forceinline__ void push(int code)
+    {
+        if (count == 0) q0 = code; else if (count == 1) q1 = code; else if (count == 2) q2 = code;
+        else if (count == 3) q3 = code; else if (count == 4) q4 = code; else q5 = code;
+        ++count;
+    }
+    __device__ __forceinline__ int pop()
+    {
+        const int head = q0;
+        q0 = q1; q1 = q2; q2 = q3; q3 = q4; q4 = q5;
+        --count;
+        return head;
+    }
+};
+
+// Best exact projection seen so far by this lane, per column group and segment (0 = base rows | the block, 1 = block 0)
+struct LaneBest {
+    double v[4][2];
+    int i[4][2];
+};
+
+// Drain the queues: rounds of up to 16 survivors (one per lane that has any), evaluated lane = pixel as in
+// evaluate_survivors; `res0..3` are this lane's residual rows for the four column groups.
+__device__ __forceinline__ void drain_survivors(CandLds& lds, int lane, SurvivorQueue& q, const double* rows_seg0,
+                                                const double* rows_seg1, const double* res0, const double* res1,
+                                                const double* res2, const double* res3, LaneBest& best)
+{
+    for (;;) {
+        const bool pending = q.count > 0;
+        const unsigned long long votes = __ballot(pending);
+        if (!votes) break;
+        const int rank = __popcll(votes & ((1ULL << lane) - 1ULL));
+        const bool active = pending && rank < kCandRound;
+        int code = 0;
+        unsigned long long row_addr = 0, res_addr = 0;
+        if (active) {
+            code = q.pop();
+            const int g = code >> 12;
+            row_addr = (unsigned long long)(uintptr_t)(((code >> 11) & 1 ? rows_seg1 : rows_seg0) + (long long)(code & 0x7FF) * N);
+            res_addr = (unsigned long long)(uintptr_t)(g == 0 ? res0 : (g == 1 ? res1 : (g == 2 ? res2 : res3)));
+        }
+        int n = __popcll(votes);
+        if (n > kCandRound) n = kCandRound;
+        unsigned long long left = votes;
+        for (int k0 = 0; k0 < n; k0 += 4) {                     // four survivors' reads in flight; slots past n repeat the last
+            double x[4], y[4];
 #pragma unroll
-            for (int i = 0; i < kAhead; ++i) {
-                const uint4* a = tile_ptr(wave + 4 * i);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) av[i][q] = a[q * 64 + lane];
+            for (int kk = 0; kk < 4; ++kk) {
+                const int src = __builtin_ctzll(left);         // wave-uniform: the lane that put up survivor k0 + kk
+                if (left & (left - 1)) left &= left - 1;
+                const unsigned rl = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)row_addr, src);
+                const unsigned rh = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(row_addr >> 32), src);
+                const unsigned sl = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)res_addr, src);
+                const unsigned sh = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(res_addr >> 32), src);
+                x[kk] = ((const double*)(uintptr_t)(((unsigned long long)rh << 32) | rl))[lane];
+                y[kk] = ((const double*)(uintptr_t)(((unsigned long long)sh << 32) | sl))[lane];
             }
 #pragma unroll
-            for (int i = 0; i < kPerWave; ++i) {
-                const int tile = wave + 4 * i;
-                if (i == 2) { MPC_FETCH_IDS(u + (int)gridDim.x) }
-                if (i == 6) { MPC_FETCH_ROWS(u + (int)gridDim.x) }
-                if (tile < ntiles) {
-                    const f32x4 acc = filter_tile_mfma(av[i % kAhead], r_hi, r_lo);
-                    if (i + kAhead < kPerWave && tile + 4 * kAhead < ntiles) {
-                        const uint4* a = tile_ptr(tile + 4 * kAhead);
+            for (int kk = 0; kk < 4; ++kk) lds.prod[(k0 + kk) * kStageStride + lane] = x[kk] * y[kk];
+        }
+        wave_lds_sync();
+        if (lane < n) {
+            const double* pr = lds.prod + lane * kStageStride;
+            double tot = 0.0;
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) av[i % kAhead][q] = a[q * 64 + lane];
+            for (int j = 0; j < N; ++j) tot += pr[j];
+            lds.res[lane] = tot;
+        }
+        wave_lds_sync();
+        if (active) {
+            const double p = lds.res[rank];
+            const int g = code >> 12, seg = (code >> 11) & 1, row = code & 0x7FF;
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg)
+#pragma unroll
+                for (int ss = 0; ss < 2; ++ss)
+                    if (g == gg && seg == ss && __builtin_fabs(p) > __builtin_fabs(best.v[gg][ss])) {
+                        best.v[gg][ss] = p;
+                        best.i[gg][ss] = row;
+                    }
+        }
+        wave_lds_sync();
+    }
+}
+
+}  // namespace
+
+// Base rows and (steps > 0) DetailBasis[0] for up to 64 tile-channels of one channel's active list per wave.
+#ifndef MPC_WAVE_OCC
+#define MPC_WAVE_OCC 2
+#endif
+__global__ __launch_bounds__(64, MPC_WAVE_OCC) void mp_filter_wave_kernel(const FilterArgs fa, int cur, int with_detail0, int force_groups)
+{
+    __shared__ CandLds s_cand;
+    const int lane = threadIdx.x;
+    const int slot = lane & 15, sub = lane >> 4;
+    if (blockIdx.x == 0 && lane < 3) fa.counters_out[(cur ^ 1) * 3 + lane] = 0;      // next step's active counts
+    const int n0 = (int)scalar_counter(fa.counters_in, cur * 3 + 0), n1 = (int)scalar_counter(fa.counters_in, cur * 3 + 1),
+              n2 = (int)scalar_counter(fa.counters_in, cur * 3 + 2);
+    // column groups per wave: as many as it takes to give every wave of the grid about one unit (small batches are
+    // latency-bound: spread them thin; large ones amortise each dictionary tile read over 64 tile-channels)
+    int groups = force_groups > 0 ? force_groups : (n0 + n1 + n2 + 16 * (int)gridDim.x - 1) / (16 * (int)gridDim.x);
+    groups = __builtin_amdgcn_readfirstlane(groups < 1 ? 1 : (groups > 4 ? 4 : groups));
+    const int per_unit = 16 * groups;
+    const int g0 = (n0 + per_unit - 1) / per_unit, g1 = (n1 + per_unit - 1) / per_unit, g2 = (n2 + per_unit - 1) / per_unit;
+    const int ntiles = kBaseFilterTiles + (with_detail0 ? kBlockFilterTiles : 0);
+    for (int u = blockIdx.x; u < g0 + g1 + g2; u += gridDim.x) {
+        const int ch = __builtin_amdgcn_readfirstlane(u < g0 ? 0 : (u < g0 + g1 ? 1 : 2));
+        const int first = (u - (ch == 0 ? 0 : (ch == 1 ? g0 : g0 + g1))) * per_unit;
+        const int n_act = ch == 0 ? n0 : (ch == 1 ? n1 : n2);
+        const int* act = ch == 0 ? fa.act[0] : (ch == 1 ? fa.act[1] : fa.act[2]);
+        const uint16_t* tiles0 = ch == 0 ? fa.block0_f32[0] : (ch == 1 ? fa.block0_f32[1] : fa.block0_f32[2]);
+        const double* block0 = ch == 0 ? fa.block0[0] : (ch == 1 ? fa.block0[1] : fa.block0[2]);
+
+        int tc[4];
+        bool ok[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int pos = first + 16 * g + slot;
+            ok[g] = g < groups && pos < n_act;
+            tc[g] = act[ok[g] ? pos : first];
+        }
+        bf16x8 bh[4][2], bl[4][2];
+        float window[4];
+        bool live[4], has0[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            window[g] = 0.0f; live[g] = false; has0[g] = false;
+            if (g < groups) {
+                bool nz;
+                const double ss = load_b_global(bh[g], bl[g], fa.r + (long long)tc[g] * N, lane, nz);
+                window[g] = 2.0f * (kFilterSlack * (float)__builtin_sqrt(ss) + kFilterAbs);
+                live[g] = ok[g] && nz;                          // an all-zero residual projects to 0 everywhere: index -1
+                has0[g] = with_detail0 && ok[g] && nblk_has0(fa.nblk[tc[g]]);
+            }
+        }
+        auto tile_ptr = [&](int tile) {
+            return (const uint4*)(tile < kBaseFilterTiles ? fa.base_f32 + tile * 2048 : tiles0 + (tile - kBaseFilterTiles) * 2048) + lane;
+        };
+
+        // ---- pass 1: largest approximation per lane (its rows: 16*tile + 4*sub + v), base rows and block 0 apart
+        float mb[4] = {0.0f, 0.0f, 0.0f, 0.0f}, md[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        {
+            uint4 a[4], nxt[4];                                 // one tile (4 x 16 B per lane) in flight ahead of the MFMAs
+            const uint4* p0 = tile_ptr(0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[q] = p0[q * 64];
+            for (int tile = 0; tile < ntiles; ++tile) {
+                const uint4* pn = tile_ptr(tile + 1 < ntiles ? tile + 1 : tile);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) nxt[q] = pn[q * 64];
+                const bool is_base = tile < kBaseFilterTiles;
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    if (g < groups) {
+                        const float m = max_abs4(filter_tile_mfma(a, bh[g], bl[g]));
+                        mb[g] = fmaxf(mb[g], is_base ? m : 0.0f);
+                        md[g] = fmaxf(md[g], is_base ? 0.0f : m);
                     }
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) s_p[(tile * 16 + sub * 4 + v) * kFilterGroup + slot] = acc[v];
+                for (int q = 0; q < 4; ++q) a[q] = nxt[q];
+            }
+        }
+        float thr[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float b = mb[g], d = md[g];
+            b = fmaxf(b, __shfl_xor(b, 16)); b = fmaxf(b, __shfl_xor(b, 32));
+            d = fmaxf(d, __shfl_xor(d, 16)); d = fmaxf(d, __shfl_xor(d, 32));
+            const float top = has0[g] ? fmaxf(b, d) : b;      // one threshold for base rows and block 0
+            thr[g] = top - window[g];
+            if (sub == 0 && ok[g]) fa.approx_max[tc[g]] = top;
+        }
+
+        // ---- pass 2: the same MFMAs again; rows at or above the threshold queue up for exact evaluation
+        LaneBest best;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int sg = 0; sg < 2; ++sg) { best.v[g][sg] = 0.0; best.i[g][sg] = -1; }
+        SurvivorQueue queue;
+        const double* res0 = fa.r + (long long)tc[0] * N;
+        const double* res1 = fa.r + (long long)tc[1] * N;
+        const double* res2 = fa.r + (long long)tc[2] * N;
+        const double* res3 = fa.r + (long long)tc[3] * N;
+        {
+            uint4 a[4], nxt[4];
+            const uint4* p0 = tile_ptr(0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[q] = p0[q * 64];
+            for (int tile = 0; tile < ntiles; ++tile) {
+                const uint4* pn = tile_ptr(tile + 1 < ntiles ? tile + 1 : tile);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) nxt[q] = pn[q * 64];
+                const bool is_base = tile < kBaseFilterTiles;
+                const int row0 = (is_base ? tile * 16 : (tile - kBaseFilterTiles) * 16) + sub * 4;
+                const int limit = is_base ? fa.num_base : fa.rows0;
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    if (g < groups) {
+                        const f32x4 acc = filter_tile_mfma(a, bh[g], bl[g]);
+                        const bool wanted = live[g] && (is_base || has0[g]);
+#pragma unroll
+                        for (int v = 0; v < 4; ++v)
+                            if (wanted && !(fabsf(acc[v]) < thr[g]) && row0 + v < limit)
+                                queue.push((g << 12) | (is_base ? 0 : 0x800) | (row0 + v));
+                        if (__ballot(queue.count > SurvivorQueue::kCapacity - 4))
+                            drain_survivors(s_cand, lane, queue, fa.base, block0, res0, res1, res2, res3, best);
+                    }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a[q] = nxt[q];
+            }
+        }
+        drain_survivors(s_cand, lane, queue, fa.base, block0, res0, res1, res2, res3, best);
+
+        // ---- the four lanes of a slot hold interleaved rows: combine by (|value|, lower row), lane sub == 0 reports
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g >= groups) continue;
+#pragma unroll
+            for (int sg = 0; sg < 2; ++sg) {
+                keep_better(best.v[g][sg], best.i[g][sg], __shfl_xor(best.v[g][sg], 16), __shfl_xor(best.i[g][sg], 16));
+                keep_better(best.v[g][sg], best.i[g][sg], __shfl_xor(best.v[g][sg], 32), __shfl_xor(best.i[g][sg], 32));
+            }
+            if (sub == 0 && ok[g]) {
+                fa.part_val[(long long)tc[g] * kMaxParts] = best.v[g][0];
+                fa.part_idx[(long long)tc[g] * kMaxParts] = best.i[g][0];
+                if (has0[g]) {
+                    fa.cand0_val[tc[g]] = best.v[g][1];
+                    fa.cand0_row[tc[g]] = best.i[g][1];
                 }
             }
         }
-        MPC_STAMP(2)
-        __syncthreads();
-        MPC_STAMP(3)
-
-        // ---- (2) largest approximation per tile-channel.  Wave w scans base rows [128w, 128w+128) and block-0 rows
-        //          [16w, 16w+16); lane (slot, sub) takes every fourth row (conflict-free LDS reads) and keeps them.
-        {
-            float mb = 0.0f, md = 0.0f;
-#pragma unroll
-            for (int i = 0; i < 32; ++i) mb = fmaxf(mb, fabsf(s_p[(wave * 128 + 4 * i + sub) * kFilterGroup + slot]));
-            if (with_detail0) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) md = fmaxf(md, fabsf(s_p[(16 * kBaseFilterTiles + wave * 16 + 4 * i + sub) * kFilterGroup + slot]));
-            }
-            mb = fmaxf(mb, __shfl_xor(mb, 16)); mb = fmaxf(mb, __shfl_xor(mb, 32));
-            md = fmaxf(md, __shfl_xor(md, 16)); md = fmaxf(md, __shfl_xor(md, 32));
-            if (sub == 0) { s_max[0][wave][slot] = mb; s_max[1][wave][slot] = (s_flags[slot] & 2) ? md : 0.0f; }
-        }
-        MPC_STAMP(4)
-        __syncthreads();
-        MPC_STAMP(5)
-        const float top = fmaxf(fmaxf(fmaxf(s_max[0][0][slot], s_max[0][1][slot]), fmaxf(s_max[0][2][slot], s_max[0][3][slot])),
-                                fmaxf(fmaxf(s_max[1][0][slot], s_max[1][1][slot]), fmaxf(s_max[1][2][slot], s_max[1][3][slot])));
-        const float thr_b = top - window, thr_d = thr_b;     // one threshold for base rows and block 0
-
-        // ---- (3) the rows that can be the maximum (second read of the approximations), then their exact values
-        const int tc = s_tc[slot];
-        const int flags = s_flags[slot];
-        unsigned mask_b = 0, mask_d = 0;
-        if (tc >= 0 && (flags & 1)) {                       // an all-zero residual projects to 0 everywhere: index -1
-#pragma unroll
-            for (int i = 0; i < 32; ++i)
-                if (!(fabsf(s_p[(wave * 128 + 4 * i + sub) * kFilterGroup + slot]) < thr_b)) mask_b |= 1u << i;
-            mask_b &= low_bits((fa.num_base - wave * 128 - sub + 3) >> 2);      // rows past the dictionary's end (zero pads)
-            if (flags & 2) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (!(fabsf(s_p[(16 * kBaseFilterTiles + wave * 16 + 4 * i + sub) * kFilterGroup + slot]) < thr_d)) mask_d |= 1u << i;
-                mask_d &= low_bits((rows0 - wave * 16 - sub + 3) >> 2);
-            }
-        }
-        __syncthreads();                                    // every wave is past its last read of s_p: its space now takes the products
-        double bv, dv;
-        int bi, di;
-        evaluate_survivors(reinterpret_cast<CandLds*>(s_p)[wave], s_r, lane, mask_b, mask_d, wave * 128, wave * 16, fa.base,
-                           ch == 0 ? fa.block0[0] : (ch == 1 ? fa.block0[1] : fa.block0[2]), bv, bi, dv, di);
-        MPC_STAMP(6)
-        // the four lanes of a slot hold interleaved rows: combine by (|value|, lower row)
-        keep_better(bv, bi, __shfl_xor(bv, 16), __shfl_xor(bi, 16));
-        keep_better(bv, bi, __shfl_xor(bv, 32), __shfl_xor(bi, 32));
-        keep_better(dv, di, __shfl_xor(dv, 16), __shfl_xor(di, 16));
-        keep_better(dv, di, __shfl_xor(dv, 32), __shfl_xor(di, 32));
-        if (sub == 0) {
-            s_val[0][wave][slot] = bv; s_idx[0][wave][slot] = bi;
-            s_val[1][wave][slot] = dv; s_idx[1][wave][slot] = di;
-        }
-        MPC_STAMP(7)
-        __syncthreads();
-        MPC_STAMP(8)
-        if (t < kFilterGroup && tc >= 0) {                  // t == slot; waves hold ascending row ranges
-            bv = s_val[0][0][t]; bi = s_idx[0][0][t];
-            dv = s_val[1][0][t]; di = s_idx[1][0][t];
-            for (int k = 1; k < 4; ++k) {
-                keep_better(bv, bi, s_val[0][k][t], s_idx[0][k][t]);
-                keep_better(dv, di, s_val[1][k][t], s_idx[1][k][t]);
-            }
-            fa.part_val[(long long)tc * kMaxParts] = bv;
-            fa.part_idx[(long long)tc * kMaxParts] = bi;
-            fa.approx_max[tc] = top;
-            if (flags & 2) {
-                fa.cand0_val[tc] = dv;
-                fa.cand0_row[tc] = di;
-            }
-        }
-        MPC_STAMP(9)
-        __syncthreads();
-        MPC_STAMP(10)
     }
-    MPC_STAMP_END()
-#undef MPC_FETCH_IDS
-#undef MPC_FETCH_ROW
-#undef MPC_FETCH_ROWS
-#undef MPC_STAGE
 }
 
 // Row range `part` of `row_parts` of a block with `rows` rows: [lo, hi)
@@ -1392,6 +1462,9 @@ int enqueue_pursuit(const DictDevice& dict, const Workspace& ws, const FrameInpu
     const unsigned max_slabs = lists * (unsigned)((per_list + 255) / 256);
     const unsigned slots = (unsigned)(sweep_waves > 0 ? sweep_waves : 3072);
     auto clampu = [](unsigned v, unsigned hi) { return v < hi ? (v ? v : 1u) : hi; };
+    // the wave-autonomous filter kernels hold 2 waves per SIMD; experiments: MPC_WAVE_SLOTS, MPC_GROUPS
+    static const unsigned wave_slots = [] { const char* v = std::getenv("MPC_WAVE_SLOTS"); return v && *v ? (unsigned)std::atoi(v) : 2048u; }();
+    static const int force_groups = [] { const char* v = std::getenv("MPC_GROUPS"); return v && *v ? std::atoi(v) : 0; }();
     hipLaunchKernelGGL(mp_init_kernel, dim3(clampu((unsigned)((n + 2) / 3), 16384u)), dim3(64), 0, s, ws, in, tc_begin, n);
     for (int step = 0; step < K; ++step) {
         const int cur = step & 1;
@@ -1412,8 +1485,8 @@ int enqueue_pursuit(const DictDevice& dict, const Workspace& ws, const FrameInpu
         }
         if (base_events) (void)hipEventRecord(static_cast<hipEvent_t>(base_events[2 * step]), s);
         if (filtered)
-            hipLaunchKernelGGL(mp_filter_kernel, dim3(clampu(lists * (unsigned)((per_list + 15) / 16), 768u)), dim3(256), 0, s,
-                               filter_args(ws, dict, cur), cur, step > 0 ? 1 : 0);
+            hipLaunchKernelGGL(mp_filter_wave_kernel, dim3(clampu(lists * (unsigned)((per_list + 15) / 16), wave_slots)), dim3(64), 0, s,
+                               filter_args(ws, dict, cur), cur, step > 0 ? 1 : 0, force_groups);
         else
             hipLaunchKernelGGL(mp_base_kernel, dim3(clampu(max_groups * (unsigned)(parts + 1), slots)), dim3(64), 0, s, ws, dict,
                                cur, parts, step > 0 ? 1 : 0, (int)slots);
