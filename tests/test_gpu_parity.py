@@ -321,3 +321,78 @@ def test_quality_sweep_on_a_crop_bytes_equal_oracle(gpu, oracle, bpp):
     ctx = ia.create_compression_context(32, 8, bpp, device=0)
     assert ctx.encode_image(rgb) == oracle.OracleContext(32, 8, bpp).encode_image(rgb)
     ctx.close()
+
+
+# ---- the MFMA filter: records must not depend on it ------------------------------------------------------------------
+
+def _adversarial_vectors():
+    """Inputs that stress the filter's threshold logic: exact ties (mirror-symmetric and constant tiles), magnitudes from
+    the f32 subnormal range to beyond the f32 range, impulses, residuals that are rounding noise after the DC atom."""
+    rng = np.random.default_rng(2024)
+    v = []
+    x, y = np.meshgrid(np.arange(8), np.arange(8))
+    for f in (x, y, x + y, x - y, (x - 3.5) ** 2, np.abs(x - 3.5) + np.abs(y - 3.5), (x ^ y) & 1, (x // 4) * 2 + (y // 4)):
+        v.append(f.reshape(-1).astype(np.float64) * 17.0)                       # symmetric patterns: exact ties
+        v.append(f.T.reshape(-1).astype(np.float64) * 17.0 + 3.0)
+    for c in (1.0, 128.0, 255.0, 0.1, 1e-3):
+        v.append(np.full(64, c))                                               # flat: residual after DC is rounding noise
+    for k in (0, 7, 27, 63):
+        e = np.zeros(64); e[k] = 200.0; v.append(e)                             # impulses
+    base = rng.integers(0, 256, (6, 64)).astype(np.float64)
+    for scale in (1e-300, 1e-160, 1e-45, 1e-38, 1e-30, 1e-10, 1.0, 1e10, 1e30, 1e38, 1e39, 1e150, 1e300):
+        v.extend(list(base * scale))                                           # f32 under/overflow on the filter side
+    v.extend(list(rng.standard_normal((40, 64)) * 1e-20))
+    v.append(np.zeros(64))
+    return np.array(v)
+
+
+@pytest.mark.parametrize("channel", [0, 2])
+def test_filter_adversarial_vectors_bit_exact(ctx32, octx32, channel):
+    v = _adversarial_vectors()
+    v = v[np.abs(v).max(axis=1) < 1e6]          # beyond that round(p / q) leaves the int range in the reference (UB there)
+    counts, choices, energy, swept = ctx32.calc_mp(channel, v)
+    for i in range(v.shape[0]):
+        cnt, d, k, res, S = octx32.calc_mp(channel, v[i])
+        assert counts[i] == cnt, i
+        n = min(cnt + 1, 32)
+        assert (choices["deltaId"][i, :n] == d[:n]).all(), i
+        assert (choices["intCoeff"][i, :n] == k[:n]).all(), i
+        assert swept[i] == S, i
+
+
+def test_filter_adversarial_vectors_tiny_quant(ctx32, octx32):
+    """a quantisation step far below the data keeps every pursuit alive for all 32 steps, whatever the magnitude: the
+    filter sees residuals shrinking towards rounding noise with deep block lists"""
+    v = _adversarial_vectors()
+    v = v[np.abs(v).max(axis=1) < 1e100]                       # round(p / q) must stay inside int range in the reference too
+    scale = np.maximum(np.abs(v).max(axis=1), 1e-290)
+    for i in range(0, v.shape[0], 16):
+        vv = v[i:i + 16]
+        for j in range(vv.shape[0]):
+            q = np.full(32, scale[i + j] * 2.0 ** -20)
+            counts, choices, energy, swept = ctx32.calc_mp(0, vv[j:j + 1], quant_k=q)
+            cnt, d, k, res, S = octx32.calc_mp(0, vv[j], quant=q)
+            assert counts[0] == cnt, (i + j)
+            n = min(cnt + 1, 32)
+            assert (choices["deltaId"][0, :n] == d[:n]).all(), (i + j)
+            assert (choices["intCoeff"][0, :n] == k[:n]).all(), (i + j)
+            assert swept[0] == S
+
+
+def test_filter_equals_exact_sweep_on_a_whole_frame(gpu, oracle, monkeypatch):
+    """the product's own exhaustive sweep (every row correlated in double, MPC_FILTER=0) and the filtered path must
+    agree on every record of a 1080p frame and of a K=32 frame -- 100 000+ pursuits, no sampling"""
+    import imageexperiments_amd as ia
+    for (w, h, K, seed) in ((1920, 1080, 8, 4242), (640, 480, 32, 99)):
+        rgb = oracle.synth_frame(w, h, seed)
+        ctx = ia.create_compression_context(K, 8, 3.5, device=0)
+        monkeypatch.setenv("MPC_FILTER", "1")
+        a = ctx.encode_tiles(rgb)
+        monkeypatch.setenv("MPC_FILTER", "0")
+        b = ctx.encode_tiles(rgb)
+        monkeypatch.delenv("MPC_FILTER")
+        ctx.close()
+        assert (a[0] == b[0]).all()
+        assert (a[1]["deltaId"] == b[1]["deltaId"]).all() and (a[1]["intCoeff"] == b[1]["intCoeff"]).all()
+        assert (a[2].view(np.uint64) == b[2].view(np.uint64)).all()
+        assert (a[3] == b[3]).all()
