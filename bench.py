@@ -30,6 +30,7 @@ WORKLOADS = {
 }
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F64_VALU_PEAK_GOPS = 256 * 4 * 16 * 2.4  # 256 CU x 4 SIMD x 16 f64 lanes/clk x 2.4 GHz = 39 321 G instr-lanes/s
+BF16_MFMA_PEAK_TFLOPS = 2516.8         # MI355X_MICROARCH.md: dense bf16 MFMA = 16 x the 157.3 TF f32 rate
 
 
 def synth_frame(W, H, seed):
@@ -160,7 +161,7 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    ctx.kernel_timing(True)                                  # HIP events around every base-sweep launch, on this stream
+    ctx.kernel_timing(True)                                  # HIP events around every launch of the dominant kernel
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
@@ -175,17 +176,22 @@ def main():
     ctx.kernel_timing(False)
     pursuit_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))     # all kernels of one step's K-step pursuit
     swept_total = int(d_swept.to(torch.int64).sum().item())             # S summed over this rank's tile-channels
-    sweeps = int(torch.clamp(d_counts.to(torch.int64) + 1, max=K).sum().item())   # min(count+1, K) per tile-channel
-    # algorithmic bytes = 64 * sizeof(double) * rows correlated.  The base sweep correlates 510 rows
-    # per executed sweep; the remaining S - 510*sweeps rows belong to the detail kernels.
-    base_bytes_per_step = 64 * 8 * 510 * sweeps
-    base_ms = base_ms_total / max(base_launches, 1)                     # average duration of ONE base-sweep launch
-    base_bytes_per_launch = base_bytes_per_step * args.steps / max(base_launches, 1)
-    # launches of the two internal streams overlap, so the machine-level rate of this kernel is bytes over the
-    # UNION of its launch intervals (equals bytes-per-launch / avg duration when nothing overlaps)
-    achieved_gbs = base_bytes_per_step * args.steps / (base_busy_ms * 1e-3) / 1e9
-    sweep_bytes = 64 * 8 * swept_total
-    valu_gops = 2 * 64 * 510 * sweeps * args.steps / (base_busy_ms * 1e-3) / 1e9   # v_mul_f64 + v_add_f64 lanes/s in the base sweep
+    # tile-channels active in pursuit step s = those with count >= s (count = K: all K steps)
+    cnt_hist = torch.bincount(d_counts.to(torch.int64).flatten().clamp(0, K), minlength=K + 1).cpu().numpy()
+    active = np.array([int(cnt_hist[s:].sum()) for s in range(K)], dtype=np.int64)
+    sweeps = int(active.sum())                                          # = sum over tile-channels of min(count+1, K)
+    # The dominant kernel (mp_filter_wave_kernel) runs the base rows (512 with the zero pads; + 64 of DetailBasis[0] from
+    # step 1 on) of every active tile-channel through the matrix cores TWICE (maximum, then threshold), each product as
+    # three bf16 MFMAs (hi*hi + hi*lo + lo*hi): executed MFMA flops per launch = 2 passes x 3 x 2*64*rows x tile-channels.
+    rows_per_step = np.array([512 + (64 if s > 0 else 0) for s in range(K)], dtype=np.int64)
+    mfma_flops_per_step = float((active * rows_per_step).sum()) * 2 * 3 * 2 * 64
+    # what the reference's algorithm asks of the same rows: one 64-term dot product per (tile-channel, row)
+    algorithmic_flops_per_step = float((active * np.array([510 + (63 if s > 0 else 0) for s in range(K)])).sum()) * 2 * 64
+    base_ms = base_ms_total / max(base_launches, 1)                     # average duration of ONE launch of it
+    # launches on the internal streams overlap, so the machine-level rate of this kernel is work over the UNION of its
+    # launch intervals (equals work-per-launch / average duration when nothing overlaps)
+    achieved_tflops = mfma_flops_per_step * args.steps / (base_busy_ms * 1e-3) / 1e12
+    sweep_bytes = 64 * 8 * swept_total                                  # 64 * sizeof(double) per row correlated
 
     if rank == 0:
         pixels_per_step = frames * W * H
@@ -216,19 +222,24 @@ def main():
                                 + (" + RCCL all-reduce of the histograms" if world > 1 else "")
                                 + "; host entropy stage (byte-identical container) not in the timed region",
                        "tiles_per_rank": tiles},
-            "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "mp_base_kernel", "kernel_avg_ms": round(base_ms, 5), "kernel_launches_per_step": base_launches // args.steps,
+            "roofline": {"bound": "mfma", "achieved": round(achieved_tflops, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved_tflops / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                         "kernel": "mp_filter_wave_kernel", "kernel_avg_ms": round(base_ms, 5),
+                         "kernel_launches_per_step": base_launches // args.steps,
                          "kernel_busy_ms_per_step": round(base_busy_ms / args.steps, 4),
-                         "algorithmic_bytes_per_launch": int(base_bytes_per_launch),
+                         "mfma_flops_per_launch": int(mfma_flops_per_step * args.steps / max(base_launches, 1)),
+                         "reference_flops_per_launch": int(algorithmic_flops_per_step * args.steps / max(base_launches, 1)),
+                         "reference_TFLOPs_equivalent": round(algorithmic_flops_per_step * args.steps / (base_busy_ms * 1e-3) / 1e12, 2),
                          "whole_pursuit": {"ms_per_step": round(pursuit_ms, 4), "algorithmic_bytes_per_step": sweep_bytes,
                                            "GB_per_s": round(sweep_bytes / (pursuit_ms * 1e-3) / 1e9, 1),
-                                           "swept_rows_per_tile": round(swept_total / tiles, 1)},
-                         "note": "algorithmic bytes = 64*8*rows correlated (SURVEY 8d); dictionary rows are served by the scalar "
-                                 "cache/L2, so this exceeds real memory traffic by design (traffic = PMC FETCH/WRITE of the whole "
-                                 "step, profiles/r01_pmc_*.json); the unit that binds is f64 VALU issue (f64_valu)",
-                         "f64_valu": {"achieved_Ginstr_lanes": round(valu_gops, 1), "peak": F64_VALU_PEAK_GOPS,
-                                      "frac": round(valu_gops / F64_VALU_PEAK_GOPS, 4)}},
+                                           "swept_rows_per_tile": round(swept_total / tiles, 1),
+                                           "tile_channel_steps": sweeps},
+                         "note": "dominant kernel = the filtered base sweep: bf16 MFMA approximations of every row select the few "
+                                 "rows whose exact double dot product can be the maximum (records stay bit-identical); achieved = "
+                                 "executed MFMA flops (2 passes x 3 split-bf16 products) over the union of its launch intervals; "
+                                 "the kernel is bound by memory latency and the serial exact evaluations, not by the matrix cores "
+                                 "(DESIGN.md); traffic = PMC FETCH/WRITE bytes of a whole step (profiles/r01_pmc_*.json); "
+                                 "whole_pursuit counts SURVEY 8(d)'s 64*8 bytes per row the reference correlates"},
         }
         if not args.no_cpu and world == 1:
             line["cpu_baseline"] = cpu_baseline(W, H, K, q, host_frames[0], args.cpu_cols)
