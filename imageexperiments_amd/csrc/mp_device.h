@@ -8,17 +8,16 @@
 //   per step s = 0..K-1:
 //     bucket   (s>0) prefix-sum the per-block item counts, emit chunk descriptors
 //     fill     (s>0) scatter (tile-channel, block) items into their block's bucket
-//     base     correlate r with the 510 shared base atoms                          (Select, MatchingPursuit.cpp:7-25)
-//              and (s>0) with DetailBasis[0], the block the DC atom unlocks for nearly every tile (no bucketing)
-//     detail   (s>0) correlate r with every other unlocked detail block, bucketed by (channel, block)
-//     finish   argmax in dictionary order, quantise, record, residual update, unlock block, compact
-//                                                                                   (MatchingPursuit.cpp:55-71)
-// Why this shape: every sweep is the same loop -- 64 tile-channels per wave (lane = tile-channel, its residual
-// in 128 VGPRs) against a run of dictionary rows that is wave-uniform and arrives through the scalar cache as
-// SGPR operands of v_mul_f64: one s_load'ed double and one VGPR double per multiply-add, no LDS or vector-memory
-// traffic per MAC, dot products in the reference's sequential order, argmax in-register in index order.
+//     filter   the 510 shared base atoms and (s>0) DetailBasis[0], the block the DC atom unlocks for nearly every
+//              tile (no bucketing): best exact projection of each                  (Select, MatchingPursuit.cpp:7-25)
+//     detail   (s>0) every other unlocked detail block, bucketed by (channel, block)
+//     finish   argmax in dictionary order, quantise, record, unlock block, compact  (MatchingPursuit.cpp:55-71)
+//     update   residual update                                                      (mathvector.cpp:116-148)
+// filter/detail find the maximum without correlating every row in double: bf16 matrix-core approximations with a
+// proven error bound select the one or two rows per tile-channel that can win, and only those are evaluated in the
+// reference's sequential double arithmetic (mp_kernels.hip).  The exhaustive double sweeps remain as a cross-check.
 // The base rows are common to all tile-channels; detail blocks differ per tile-channel, so the (tile-channel,
-// block) pairs of a step are bucketed by block and a wave takes up to 64 tile-channels of ONE bucket.
+// block) pairs of a step are bucketed by block and one MFMA operand tile serves 16 tile-channels of ONE bucket.
 // Active tile-channels are kept in per-channel lists (the detail rows are per channel).
 #pragma once
 #include <cstddef>

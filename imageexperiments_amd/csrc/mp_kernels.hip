@@ -1,16 +1,17 @@
 // mp_kernels.hip -- product: hand-written gfx950 (CDNA4, wave64) kernels of the quantized
-// matching-pursuit tile encoder.  See mp_device.h for the pipeline.  No MFMA; IEEE double with
-// separately rounded mul/add (-ffp-contract=off): integer outputs must equal the reference's
-// double path (MatchingPursuit.cpp:39-74) bit for bit.
-//
-// All three sweep kernels share one loop: a 64-term sequential dot product
+// matching-pursuit tile encoder.  See mp_device.h for the pipeline.  Integer outputs must equal the reference's
+// double path (MatchingPursuit.cpp:39-74) bit for bit, so every value that decides anything is IEEE double with
+// separately rounded mul/add (-ffp-contract=off) in the reference's order:
 //     tot = 0; tot += row[j] * r[j]   (j ascending, mathmatrix.cpp:436-444)
-// per dictionary row, where r (one tile-channel per lane) lives in 128 VGPRs for the whole loop and the
-// row is wave-uniform and arrives through the scalar data cache (s_load_dwordx16 -> SGPR operand of
-// v_mul_f64).  SMEM returns out of
-// order, so the only usable wait is lgkmcnt(0): the loop keeps exactly ONE 16-double group load in
-// flight, issued right after the wait for the previous group, and relies on 2-3 co-resident waves per
-// SIMD to cover what 15 multiply-adds do not (measured: tools/ubench_scalar_sweep.hip).
+// Two ways to find the row Select() returns:
+//   * filtered sweeps (default): split-bfloat16 MFMA approximations of ALL rows with a proven error bound pick the
+//     one or two rows per tile-channel that can be the maximum; only those get the dot product above
+//     (mp_filter_wave_kernel, mp_detail_filter_kernel; comment block "filtered sweeps").
+//   * exhaustive sweeps (MPC_FILTER=0, the product's own cross-check): every row gets it -- r (one tile-channel per
+//     lane) lives in 128 VGPRs, the row is wave-uniform and arrives through the scalar data cache (s_load_dwordx16
+//     -> SGPR operand of v_mul_f64).  SMEM returns out of order, so the only usable wait is lgkmcnt(0): the loop
+//     keeps exactly ONE 16-double group load in flight (mp_base_kernel, mp_detail_kernel; measured:
+//     tools/ubench_scalar_sweep.hip).
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include <stdint.h>

@@ -509,7 +509,7 @@ mpc_status mpc_calc_mp_batch(mpc_context* c, int channel, const double* quant_k,
     return MPC_OK;
 }
 
-// live timing of the dominant kernel (mp_base_kernel) with HIP events on the launch stream
+// live timing of the dominant kernel (mp_filter_wave_kernel; mp_base_kernel with MPC_FILTER=0) with HIP events on the launch stream
 void mpc_kernel_timing_enable(mpc_context* c, int on) {
     if (!c) return;
     c->timing = on != 0;

@@ -139,7 +139,7 @@ mpc_status mpc_calc_mp_batch(mpc_context* ctx, int channel, const double* quant_
  * joined to the caller's stream with events); at most 262144 tiles are in flight. */
 mpc_status mpc_reserve(mpc_context* ctx, long long max_tiles);
 
-/* Live timing of the dominant kernel (the base sweep, mp_base_kernel): while enabled every launch of it is
+/* Live timing of the dominant kernel (the filtered base sweep, mp_filter_wave_kernel): while enabled every launch of it is
  * bracketed by HIP events on the stream it is launched on.  mpc_kernel_timing_read synchronises and returns, for
  * the launches since the last read/enable: the summed duration, their number, and (busy_ms, may be NULL) the
  * length of the union of their intervals -- launches of the two internal streams overlap.  Measurement only. */
