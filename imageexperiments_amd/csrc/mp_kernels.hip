@@ -522,10 +522,43 @@ __device__ __forceinline__ double load_b_global(bf16x8 (&hi)[2], bf16x8 (&lo)[2]
     return ss;
 }
 
-__device__ __forceinline__ float max_abs4(const f32x4& a)
-{
-    return fmaxf(fmaxf(fabsf(a[0]), fabsf(a[1])), fmaxf(fabsf(a[2]), fabsf(a[3])));
-}
+// The two largest approximations a lane has seen among its rows of one segment, and the row of the largest: if the
+// runner-up of the whole tile-channel stays below the threshold, the single survivor is known after pass 1 and the
+// second MFMA pass is not needed for it.
+struct TopTwo {
+    float m1 = 0.0f, m2 = 0.0f;
+    int row = -1;
+    bool odd = false;                                  // saw a NaN or an infinity: leave it to pass 2
+    __device__ __forceinline__ void see(float value, int r)
+    {
+        const float a = fabsf(value);
+        const bool gt1 = a > m1, gt2 = a > m2;
+        m2 = gt1 ? m1 : (gt2 ? a : m2);
+        row = gt1 ? r : row;
+        m1 = gt1 ? a : m1;
+        odd = odd || !(a <= 3.4028234663852886e38f);
+    }
+    // fold in the three other lanes that hold rows of the same tile-channel: top = its largest approximation, second =
+    // its runner-up (a tie for the top counts as a runner-up), mine = this lane owns the unique top row
+    __device__ __forceinline__ void across_lanes(float& top, float& second, bool& mine, bool& any_odd) const
+    {
+        top = fmaxf(m1, __shfl_xor(m1, 16));
+        top = fmaxf(top, __shfl_xor(top, 32));
+        const bool at_top = m1 == top;
+        int n_top = at_top ? 1 : 0;
+        n_top += __shfl_xor(n_top, 16);
+        n_top += __shfl_xor(n_top, 32);
+        float rest = at_top ? m2 : m1;
+        rest = fmaxf(rest, __shfl_xor(rest, 16));
+        rest = fmaxf(rest, __shfl_xor(rest, 32));
+        second = n_top > 1 ? top : rest;
+        mine = at_top && n_top == 1;
+        int o = odd ? 1 : 0;
+        o |= __shfl_xor(o, 16);
+        o |= __shfl_xor(o, 32);
+        any_odd = o != 0;
+    }
+};
 
 // Per-lane FIFO of surviving rows waiting for their exact evaluation.  code = group << 12 | segment << 11 | row.
 struct SurvivorQueue {
@@ -672,8 +705,8 @@ __global__ __launch_bounds__(64, MPC_WAVE_OCC) void mp_filter_wave_kernel(const 
             return (const uint4*)(tile < kBaseFilterTiles ? fa.base_f32 + tile * 2048 : tiles0 + (tile - kBaseFilterTiles) * 2048) + lane;
         };
 
-        // ---- pass 1: largest approximation per lane (its rows: 16*tile + 4*sub + v), base rows and block 0 apart
-        float mb[4] = {0.0f, 0.0f, 0.0f, 0.0f}, md[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        // ---- pass 1: the two largest approximations per lane (its rows: 16*tile + 4*sub + v), base rows and block 0 apart
+        TopTwo tb[4], td[4];
         {
             uint4 a[4], nxt[4];                                 // one tile (4 x 16 B per lane) in flight ahead of the MFMAs
             const uint4* p0 = tile_ptr(0);
@@ -683,41 +716,66 @@ __global__ __launch_bounds__(64, MPC_WAVE_OCC) void mp_filter_wave_kernel(const 
                 const uint4* pn = tile_ptr(tile + 1 < ntiles ? tile + 1 : tile);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) nxt[q] = pn[q * 64];
-                const bool is_base = tile < kBaseFilterTiles;
+                if (tile < kBaseFilterTiles) {
+                    const int row0 = tile * 16 + sub * 4;
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    if (g < groups) {
-                        const float m = max_abs4(filter_tile_mfma(a, bh[g], bl[g]));
-                        mb[g] = fmaxf(mb[g], is_base ? m : 0.0f);
-                        md[g] = fmaxf(md[g], is_base ? 0.0f : m);
-                    }
+                    for (int g = 0; g < 4; ++g)
+                        if (g < groups) {
+                            const f32x4 acc = filter_tile_mfma(a, bh[g], bl[g]);
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) tb[g].see(acc[v], row0 + v);
+                        }
+                } else {
+                    const int row0 = (tile - kBaseFilterTiles) * 16 + sub * 4;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        if (g < groups) {
+                            const f32x4 acc = filter_tile_mfma(a, bh[g], bl[g]);
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) td[g].see(acc[v], row0 + v);
+                        }
+                }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) a[q] = nxt[q];
             }
         }
-        float thr[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float b = mb[g], d = md[g];
-            b = fmaxf(b, __shfl_xor(b, 16)); b = fmaxf(b, __shfl_xor(b, 32));
-            d = fmaxf(d, __shfl_xor(d, 16)); d = fmaxf(d, __shfl_xor(d, 32));
-            const float top = has0[g] ? fmaxf(b, d) : b;      // one threshold for base rows and block 0
-            thr[g] = top - window[g];
-            if (sub == 0 && ok[g]) fa.approx_max[tc[g]] = top;
-        }
-
-        // ---- pass 2: the same MFMAs again; rows at or above the threshold queue up for exact evaluation
+        // thresholds; where the runner-up is below it the survivors are known already (at most one per segment)
         LaneBest best;
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int sg = 0; sg < 2; ++sg) { best.v[g][sg] = 0.0; best.i[g][sg] = -1; }
-        SurvivorQueue queue;
         const double* res0 = fa.r + (long long)tc[0] * N;
         const double* res1 = fa.r + (long long)tc[1] * N;
         const double* res2 = fa.r + (long long)tc[2] * N;
         const double* res3 = fa.r + (long long)tc[3] * N;
-        {
+        float thr[4];
+        bool second_pass[4];                                    // wave-uniform per column group
+        SurvivorQueue queue;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float top_b, second_b, top_d, second_d;
+            bool mine_b, mine_d, odd_b, odd_d;
+            tb[g].across_lanes(top_b, second_b, mine_b, odd_b);
+            td[g].across_lanes(top_d, second_d, mine_d, odd_d);
+            const float top = has0[g] ? fmaxf(top_b, top_d) : top_b;      // one threshold for base rows and block 0
+            thr[g] = top - window[g];
+            if (sub == 0 && ok[g]) fa.approx_max[tc[g]] = top;
+            // ambiguous: a runner-up at or above the threshold, a non-positive threshold (zero pads would qualify), NaN/Inf
+            const bool unclear = !(second_b < thr[g]) || (has0[g] && !(second_d < thr[g])) || !(thr[g] > 0.0f) || odd_b ||
+                                 (has0[g] && odd_d);
+            second_pass[g] = g < groups && __ballot(live[g] && unclear) != 0;
+            if (g < groups && !second_pass[g] && live[g]) {
+                if (mine_b && !(top_b < thr[g])) queue.push((g << 12) | tb[g].row);
+                if (has0[g] && mine_d && !(top_d < thr[g])) queue.push((g << 12) | 0x800 | td[g].row);
+            }
+            if (__ballot(queue.count > SurvivorQueue::kCapacity - 2))       // room for the next group's two
+                drain_survivors(s_cand, lane, queue, fa.base, block0, res0, res1, res2, res3, best);
+        }
+
+        // ---- pass 2, only for column groups with an unclear tile-channel: the same MFMAs again; rows at or above the
+        //      threshold queue up for exact evaluation
+        if (second_pass[0] || second_pass[1] || second_pass[2] || second_pass[3]) {
             uint4 a[4], nxt[4];
             const uint4* p0 = tile_ptr(0);
 #pragma unroll
@@ -731,7 +789,7 @@ __global__ __launch_bounds__(64, MPC_WAVE_OCC) void mp_filter_wave_kernel(const 
                 const int limit = is_base ? fa.num_base : fa.rows0;
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
-                    if (g < groups) {
+                    if (second_pass[g]) {
                         const f32x4 acc = filter_tile_mfma(a, bh[g], bl[g]);
                         const bool wanted = live[g] && (is_base || has0[g]);
 #pragma unroll
