@@ -110,8 +110,8 @@ struct HistParams {
 // Tile-channel numbering: tc = unit*3 + ch, unit = frame*tiles_per_frame_stripe + tx*tile_rows + (ty - begin)
 // (vector mode: tc = vector index, channel fixed).  Returns hipError_t as int.  No host synchronisation,
 // no allocation: graph-capturable.
-// side_stream/fork_event/join_event: optional second stream (+ two events) on which each step's detail branch runs
-// concurrently with its base sweep; nullptr = everything on `stream`.
+// side_stream/fork_event/join_event: optional second stream (+ two events) on which each step's residual update runs
+// beside the next step's bucket + fill kernels; nullptr = everything on `stream`.
 // base_events: optional array of 2*K hipEvent_t (as void*) recorded right before / after each base-sweep launch
 // (live per-kernel timing for bench.py's roofline); nullptr = none.
 int enqueue_pursuit(const DictDevice& dict, const Workspace& ws, const FrameInput& in, const Outputs& out,

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include <stdint.h>
+#include <type_traits>
 
 #include "mp_device.h"
 
@@ -650,12 +651,66 @@ __device__ __forceinline__ void drain_survivors(CandLds& lds, int lane, Survivor
     }
 }
 
+// f(integral_constant<0>), ..., f(integral_constant<COUNT-1>): a loop the optimiser cannot decline to unroll (register
+// arrays indexed by a loop variable that survives as a variable end up in scratch memory)
+template <int COUNT, class F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (COUNT > 0) {
+        static_for<COUNT - 1>(f);
+        f(std::integral_constant<int, COUNT - 1>{});
+    }
+}
+
+// Run body(tile, operands) over tiles first..last-1 with DEPTH tile reads (4 x 16 B per lane each) in flight ahead of
+// the MFMAs.  DEPTH 1 for large batches (four column groups per wave keep the matrix cores busy and the registers
+// full); DEPTH 4 for small ones, where a tile's MFMAs are far shorter than its L2 round trip.  last - first is a
+// multiple of 4.
+template <int DEPTH, class Ptr, class Body>
+__device__ __forceinline__ void for_each_tile(int first, int last, Ptr&& tile_ptr, Body&& body)
+{
+#define MPC_LOAD_TILE(dst_, tile_)                                                                             \
+    {                                                                                                          \
+        const uint4* p_ = tile_ptr((tile_) < last ? (tile_) : last - 1);                                       \
+        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) dst_[q_] = p_[q_ * 64];                               \
+    }
+    if constexpr (DEPTH == 1) {
+        uint4 a[4], nxt[4];
+        MPC_LOAD_TILE(a, first)
+        for (int tile = first; tile < last; ++tile) {
+            MPC_LOAD_TILE(nxt, tile + 1)
+            body(tile, a);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[q] = nxt[q];
+        }
+    } else {
+        static_assert(DEPTH == 4, "ring of four named buffers");
+        uint4 r0[4], r1[4], r2[4], r3[4];
+        MPC_LOAD_TILE(r0, first + 0)
+        MPC_LOAD_TILE(r1, first + 1)
+        MPC_LOAD_TILE(r2, first + 2)
+        MPC_LOAD_TILE(r3, first + 3)
+        for (int t0 = first; t0 < last; t0 += 4) {
+            body(t0 + 0, r0);
+            MPC_LOAD_TILE(r0, t0 + 4)
+            body(t0 + 1, r1);
+            MPC_LOAD_TILE(r1, t0 + 5)
+            body(t0 + 2, r2);
+            MPC_LOAD_TILE(r2, t0 + 6)
+            body(t0 + 3, r3);
+            MPC_LOAD_TILE(r3, t0 + 7)
+        }
+    }
+#undef MPC_LOAD_TILE
+}
+
 }  // namespace
 
 // Base rows and (steps > 0) DetailBasis[0] for up to 64 tile-channels of one channel's active list per wave.
 #ifndef MPC_WAVE_OCC
 #define MPC_WAVE_OCC 2
 #endif
+template <int MAXG, int DEPTH>
 __global__ __launch_bounds__(64, MPC_WAVE_OCC) void mp_filter_wave_kernel(const FilterArgs fa, int cur, int with_detail0, int force_groups)
 {
     __shared__ CandLds s_cand;
@@ -667,7 +722,7 @@ __global__ __launch_bounds__(64, MPC_WAVE_OCC) void mp_filter_wave_kernel(const 
     // column groups per wave: as many as it takes to give every wave of the grid about one unit (small batches are
     // latency-bound: spread them thin; large ones amortise each dictionary tile read over 64 tile-channels)
     int groups = force_groups > 0 ? force_groups : (n0 + n1 + n2 + 16 * (int)gridDim.x - 1) / (16 * (int)gridDim.x);
-    groups = __builtin_amdgcn_readfirstlane(groups < 1 ? 1 : (groups > 4 ? 4 : groups));
+    groups = __builtin_amdgcn_readfirstlane(groups < 1 ? 1 : (groups > MAXG ? MAXG : groups));
     const int per_unit = 16 * groups;
     const int g0 = (n0 + per_unit - 1) / per_unit, g1 = (n1 + per_unit - 1) / per_unit, g2 = (n2 + per_unit - 1) / per_unit;
     const int ntiles = kBaseFilterTiles + (with_detail0 ? kBlockFilterTiles : 0);
@@ -679,10 +734,10 @@ __global__ __launch_bounds__(64, MPC_WAVE_OCC) void mp_filter_wave_kernel(const 
         const uint16_t* tiles0 = ch == 0 ? fa.block0_f32[0] : (ch == 1 ? fa.block0_f32[1] : fa.block0_f32[2]);
         const double* block0 = ch == 0 ? fa.block0[0] : (ch == 1 ? fa.block0[1] : fa.block0[2]);
 
-        int tc[4];
-        bool ok[4];
+        int tc[4] = {0, 0, 0, 0};
+        bool ok[4] = {false, false, false, false};
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int g = 0; g < MAXG; ++g) {
             const int pos = first + 16 * g + slot;
             ok[g] = g < groups && pos < n_act;
             tc[g] = act[ok[g] ? pos : first];
@@ -691,7 +746,7 @@ __global__ __launch_bounds__(64, MPC_WAVE_OCC) void mp_filter_wave_kernel(const 
         float window[4];
         bool live[4], has0[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int g = 0; g < MAXG; ++g) {
             window[g] = 0.0f; live[g] = false; has0[g] = false;
             if (g < groups) {
                 bool nz;
@@ -707,38 +762,29 @@ __global__ __launch_bounds__(64, MPC_WAVE_OCC) void mp_filter_wave_kernel(const 
 
         // ---- pass 1: the two largest approximations per lane (its rows: 16*tile + 4*sub + v), base rows and block 0 apart
         TopTwo tb[4], td[4];
-        {
-            uint4 a[4], nxt[4];                                 // one tile (4 x 16 B per lane) in flight ahead of the MFMAs
-            const uint4* p0 = tile_ptr(0);
+        for_each_tile<DEPTH>(0, kBaseFilterTiles, tile_ptr, [&](int tile, const uint4 (&a)[4]) {
+            const int row0 = tile * 16 + sub * 4;
+            static_for<MAXG>([&](auto gc) {
+                constexpr int g = decltype(gc)::value;
+                if (g < groups) {
+                    const f32x4 acc = filter_tile_mfma(a, bh[g], bl[g]);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) a[q] = p0[q * 64];
-            for (int tile = 0; tile < ntiles; ++tile) {
-                const uint4* pn = tile_ptr(tile + 1 < ntiles ? tile + 1 : tile);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) nxt[q] = pn[q * 64];
-                if (tile < kBaseFilterTiles) {
-                    const int row0 = tile * 16 + sub * 4;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        if (g < groups) {
-                            const f32x4 acc = filter_tile_mfma(a, bh[g], bl[g]);
-#pragma unroll
-                            for (int v = 0; v < 4; ++v) tb[g].see(acc[v], row0 + v);
-                        }
-                } else {
-                    const int row0 = (tile - kBaseFilterTiles) * 16 + sub * 4;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        if (g < groups) {
-                            const f32x4 acc = filter_tile_mfma(a, bh[g], bl[g]);
-#pragma unroll
-                            for (int v = 0; v < 4; ++v) td[g].see(acc[v], row0 + v);
-                        }
+                    for (int v = 0; v < 4; ++v) tb[g].see(acc[v], row0 + v);
                 }
+            });
+        });
+        if (with_detail0)
+            for_each_tile<DEPTH>(kBaseFilterTiles, kBaseFilterTiles + kBlockFilterTiles, tile_ptr, [&](int tile, const uint4 (&a)[4]) {
+                const int row0 = (tile - kBaseFilterTiles) * 16 + sub * 4;
+                static_for<MAXG>([&](auto gc) {
+                    constexpr int g = decltype(gc)::value;
+                    if (g < groups) {
+                        const f32x4 acc = filter_tile_mfma(a, bh[g], bl[g]);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) a[q] = nxt[q];
-            }
-        }
+                        for (int v = 0; v < 4; ++v) td[g].see(acc[v], row0 + v);
+                    }
+                });
+            });
         // thresholds; where the runner-up is below it the survivors are known already (at most one per segment)
         LaneBest best;
 #pragma unroll
@@ -750,10 +796,10 @@ __global__ __launch_bounds__(64, MPC_WAVE_OCC) void mp_filter_wave_kernel(const 
         const double* res2 = fa.r + (long long)tc[2] * N;
         const double* res3 = fa.r + (long long)tc[3] * N;
         float thr[4];
-        bool second_pass[4];                                    // wave-uniform per column group
+        bool second_pass[4] = {false, false, false, false};    // wave-uniform per column group
         SurvivorQueue queue;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        static_for<MAXG>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
             float top_b, second_b, top_d, second_d;
             bool mine_b, mine_d, odd_b, odd_d;
             tb[g].across_lanes(top_b, second_b, mine_b, odd_b);
@@ -771,24 +817,17 @@ __global__ __launch_bounds__(64, MPC_WAVE_OCC) void mp_filter_wave_kernel(const 
             }
             if (__ballot(queue.count > SurvivorQueue::kCapacity - 2))       // room for the next group's two
                 drain_survivors(s_cand, lane, queue, fa.base, block0, res0, res1, res2, res3, best);
-        }
+        });
 
         // ---- pass 2, only for column groups with an unclear tile-channel: the same MFMAs again; rows at or above the
         //      threshold queue up for exact evaluation
-        if (second_pass[0] || second_pass[1] || second_pass[2] || second_pass[3]) {
-            uint4 a[4], nxt[4];
-            const uint4* p0 = tile_ptr(0);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) a[q] = p0[q * 64];
-            for (int tile = 0; tile < ntiles; ++tile) {
-                const uint4* pn = tile_ptr(tile + 1 < ntiles ? tile + 1 : tile);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) nxt[q] = pn[q * 64];
+        if (second_pass[0] || second_pass[1] || second_pass[2] || second_pass[3])
+            for_each_tile<DEPTH>(0, ntiles, tile_ptr, [&](int tile, const uint4 (&a)[4]) {
                 const bool is_base = tile < kBaseFilterTiles;
                 const int row0 = (is_base ? tile * 16 : (tile - kBaseFilterTiles) * 16) + sub * 4;
                 const int limit = is_base ? fa.num_base : fa.rows0;
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
+                static_for<MAXG>([&](auto gc) {
+                    constexpr int g = decltype(gc)::value;
                     if (second_pass[g]) {
                         const f32x4 acc = filter_tile_mfma(a, bh[g], bl[g]);
                         const bool wanted = live[g] && (is_base || has0[g]);
@@ -799,15 +838,13 @@ __global__ __launch_bounds__(64, MPC_WAVE_OCC) void mp_filter_wave_kernel(const 
                         if (__ballot(queue.count > SurvivorQueue::kCapacity - 4))
                             drain_survivors(s_cand, lane, queue, fa.base, block0, res0, res1, res2, res3, best);
                     }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) a[q] = nxt[q];
-            }
-        }
+                });
+            });
         drain_survivors(s_cand, lane, queue, fa.base, block0, res0, res1, res2, res3, best);
 
         // ---- the four lanes of a slot hold interleaved rows: combine by (|value|, lower row), lane sub == 0 reports
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int g = 0; g < MAXG; ++g) {
             if (g >= groups) continue;
 #pragma unroll
             for (int sg = 0; sg < 2; ++sg) {
@@ -1505,7 +1542,7 @@ int enqueue_pursuit(const DictDevice& dict, const Workspace& ws, const FrameInpu
     hipStream_t s = static_cast<hipStream_t>(stream_);
     hipStream_t side = static_cast<hipStream_t>(side_stream_);
     hipEvent_t ev_fork = static_cast<hipEvent_t>(fork_event_), ev_join = static_cast<hipEvent_t>(join_event_);
-    const bool forked = side != nullptr && ev_fork != nullptr && ev_join != nullptr && parts >= 1;
+    const bool forked = side != nullptr && ev_fork != nullptr && ev_join != nullptr;
     if (n < 1 || n > ws.cap) return (int)hipErrorInvalidValue;
     const bool filtered = parts < 1;          // sweeps through the MFMA filter instead of correlating every row exactly
     if (filtered) row_parts = 1;
@@ -1523,48 +1560,50 @@ int enqueue_pursuit(const DictDevice& dict, const Workspace& ws, const FrameInpu
     auto clampu = [](unsigned v, unsigned hi) { return v < hi ? (v ? v : 1u) : hi; };
     // the wave-autonomous filter kernels hold 2 waves per SIMD; experiments: MPC_WAVE_SLOTS, MPC_GROUPS
     static const unsigned wave_slots = [] { const char* v = std::getenv("MPC_WAVE_SLOTS"); return v && *v ? (unsigned)std::atoi(v) : 2048u; }();
+    // at most two column groups per wave would be used anyway: take the variant that spends its registers on tile reads
+    const bool small_batch = (long long)n <= 2LL * 16 * wave_slots && std::getenv("MPC_NO_SMALL") == nullptr;
     static const int force_groups = [] { const char* v = std::getenv("MPC_GROUPS"); return v && *v ? std::atoi(v) : 0; }();
     hipLaunchKernelGGL(mp_init_kernel, dim3(clampu((unsigned)((n + 2) / 3), 16384u)), dim3(64), 0, s, ws, in, tc_begin, n);
     for (int step = 0; step < K; ++step) {
         const int cur = step & 1;
-        // The detail branch of a step (bucket -> fill -> detail sweep) and its base sweep are independent: both only
-        // read the residuals and the active lists.  With a side stream they run concurrently, so the detail units
-        // fill the tail of the base sweep's last round instead of waiting for it.
-        hipStream_t ds = (forked && step > 0) ? side : s;
         if (step > 0) {
-            if (forked) {
-                (void)hipEventRecord(ev_fork, s);
-                (void)hipStreamWaitEvent(side, ev_fork, 0);
-            }
-            hipLaunchKernelGGL(mp_bucket_kernel, dim3(1), dim3(1024), 0, ds, ws, step & 1);
-            hipLaunchKernelGGL(mp_fill_kernel, dim3(clampu(max_slabs, 2048u)), dim3(256), 0, ds, ws, cur);
-            if (forked)
-                hipLaunchKernelGGL(mp_detail_kernel, dim3(clampu(max_groups * (unsigned)row_parts, slots)), dim3(64), 0, ds, ws,
-                                   dict, row_parts, (int)slots, ws.cand_val);
+            hipLaunchKernelGGL(mp_bucket_kernel, dim3(1), dim3(1024), 0, s, ws, step & 1);
+            hipLaunchKernelGGL(mp_fill_kernel, dim3(clampu(max_slabs, 2048u)), dim3(256), 0, s, ws, cur);
+            if (forked) (void)hipStreamWaitEvent(s, ev_join, 0);          // the previous step's residual update
         }
         if (base_events) (void)hipEventRecord(static_cast<hipEvent_t>(base_events[2 * step]), s);
         if (filtered)
-            hipLaunchKernelGGL(mp_filter_wave_kernel, dim3(clampu(lists * (unsigned)((per_list + 15) / 16), wave_slots)), dim3(64), 0, s,
-                               filter_args(ws, dict, cur), cur, step > 0 ? 1 : 0, force_groups);
+            if (small_batch)
+                hipLaunchKernelGGL((mp_filter_wave_kernel<2, 4>), dim3(clampu(lists * (unsigned)((per_list + 15) / 16), wave_slots)), dim3(64),
+                                   0, s, filter_args(ws, dict, cur), cur, step > 0 ? 1 : 0, force_groups);
+            else
+                hipLaunchKernelGGL((mp_filter_wave_kernel<4, 1>), dim3(clampu(lists * (unsigned)((per_list + 15) / 16), wave_slots)), dim3(64),
+                                   0, s, filter_args(ws, dict, cur), cur, step > 0 ? 1 : 0, force_groups);
         else
             hipLaunchKernelGGL(mp_base_kernel, dim3(clampu(max_groups * (unsigned)(parts + 1), slots)), dim3(64), 0, s, ws, dict,
                                cur, parts, step > 0 ? 1 : 0, (int)slots);
         if (base_events) (void)hipEventRecord(static_cast<hipEvent_t>(base_events[2 * step + 1]), s);
         if (step > 0) {
-            if (forked) {
-                (void)hipEventRecord(ev_join, side);
-                (void)hipStreamWaitEvent(s, ev_join, 0);
-            } else if (filtered) {
+            if (filtered)
                 hipLaunchKernelGGL(mp_detail_filter_kernel, dim3(clampu(max_groups * 4u, 3072u)), dim3(64), 0, s, detail_args);
-            } else {
+            else
                 hipLaunchKernelGGL(mp_detail_kernel, dim3(clampu(max_groups * (unsigned)row_parts, slots)), dim3(64), 0, s, ws,
                                    dict, row_parts, (int)slots, ws.cand_val);
-            }
         }
         hipLaunchKernelGGL(mp_finish_kernel, dim3(clampu(max_slabs, 2048u)), dim3(256), 0, s, ws, dict, out, quant_dev, K,
                            step, cur, parts, row_parts, (int)slots);
-        if (step + 1 < K)
-            hipLaunchKernelGGL(mp_update_kernel, dim3(clampu(max_groups, 4096u)), dim3(64), 0, s, ws, dict, cur);
+        if (step + 1 < K) {
+            // The residual update and the next step's bucket + fill only depend on the finish kernel, not on each other:
+            // with a side stream the update runs beside them and is joined in front of the next sweep.
+            if (forked) {
+                (void)hipEventRecord(ev_fork, s);
+                (void)hipStreamWaitEvent(side, ev_fork, 0);
+                hipLaunchKernelGGL(mp_update_kernel, dim3(clampu(max_groups, 4096u)), dim3(64), 0, side, ws, dict, cur);
+                (void)hipEventRecord(ev_join, side);
+            } else {
+                hipLaunchKernelGGL(mp_update_kernel, dim3(clampu(max_groups, 4096u)), dim3(64), 0, s, ws, dict, cur);
+            }
+        }
     }
     return (int)hipGetLastError();
 }
