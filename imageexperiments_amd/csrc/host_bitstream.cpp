@@ -3,6 +3,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
@@ -29,17 +32,66 @@ void BitWriter::put(uint64_t value, int width) {
     nbits_ += static_cast<size_t>(width);
 }
 
+void BitWriter::put_codes(const uint16_t* data, size_t n, const uint32_t* code_of, const uint8_t* length_of, size_t total_bits) {
+    if (n == 0) return;
+    words_.resize(((nbits_ + total_bits) >> 6) + 2, 0);       // everything this call writes, plus put()'s spare word
+    size_t word = nbits_ >> 6;
+    int used = static_cast<int>(nbits_ & 63);
+    uint64_t acc = used ? words_[word] >> (64 - used) : 0;     // the bits already in the current word, right-aligned
+    for (size_t i = 0; i < n; ++i) {
+        const uint16_t s = data[i];
+        const int len = length_of[s];
+        const uint64_t code = code_of[s];
+        if (used + len <= 64) {
+            acc = (len == 64) ? code : ((acc << len) | code);
+            used += len;
+            if (used == 64) { words_[word++] = acc; acc = 0; used = 0; }
+        } else {
+            const int spill = used + len - 64;                 // low `spill` bits go to the next word
+            words_[word++] = (acc << (len - spill)) | (code >> spill);
+            acc = code & ((1ULL << spill) - 1ULL);
+            used = spill;
+        }
+    }
+    words_[word] = used ? acc << (64 - used) : 0;
+    nbits_ += total_bits;
+}
+
 void BitWriter::append(const BitWriter& other) {
-    const size_t full = other.nbits_ >> 6;
-    for (size_t i = 0; i < full; ++i) put(other.words_[i], 64);
-    const int tail = static_cast<int>(other.nbits_ & 63);
-    if (tail) put(other.words_[full] >> (64 - tail), tail);
+    if (other.nbits_ == 0) return;
+    const size_t src_words = (other.nbits_ + 63) >> 6;
+    const int used = static_cast<int>(nbits_ & 63);
+    size_t word = nbits_ >> 6;
+    words_.resize(((nbits_ + other.nbits_) >> 6) + 2, 0);
+    if (used == 0) {
+        std::memcpy(words_.data() + word, other.words_.data(), src_words * sizeof(uint64_t));
+    } else {                                                   // every source word straddles two destination words
+        uint64_t carry = words_[word];
+        for (size_t i = 0; i < src_words; ++i) {
+            const uint64_t v = other.words_[i];
+            words_[word++] = carry | (v >> used);
+            carry = v << (64 - used);
+        }
+        words_[word] = carry;
+    }
+    nbits_ += other.nbits_;
+    // bits past the end must stay zero (put() ORs into the current word): the source's last word is zero-padded already,
+    // but clear what the shift may have left in the word after the new end
+    const size_t last = nbits_ >> 6;
+    const int tail = static_cast<int>(nbits_ & 63);
+    words_[last] = tail ? (words_[last] & ~((1ULL << (64 - tail)) - 1ULL)) : 0;
+    for (size_t i = last + 1; i < words_.size(); ++i) words_[i] = 0;
 }
 
 std::vector<uint8_t> BitWriter::bytes() const {
     const size_t n = (nbits_ + 7) / 8;
     std::vector<uint8_t> out(n);
-    for (size_t i = 0; i < n; ++i) out[i] = static_cast<uint8_t>(words_[i >> 3] >> (56 - 8 * (i & 7)));
+    const size_t whole = n / 8;
+    for (size_t i = 0; i < whole; ++i) {
+        const uint64_t be = __builtin_bswap64(words_[i]);       // MSB-first bit order = big-endian bytes
+        std::memcpy(out.data() + 8 * i, &be, 8);
+    }
+    for (size_t i = 8 * whole; i < n; ++i) out[i] = static_cast<uint8_t>(words_[i >> 3] >> (56 - 8 * (i & 7)));
     return out;
 }
 
@@ -253,7 +305,11 @@ struct Entry {
 
 // Huffman.cpp:46-163
 void huffman_encode(const uint16_t* data, size_t n, BitWriter& out) {
-    std::vector<int> leaf_of(65536, -1);
+    // lookup tables only as large as the largest symbol (streams of small numbers: no 64K-entry tables to clear per stream)
+    uint16_t largest = 0;
+    for (size_t i = 0; i < n; ++i) largest = std::max(largest, data[i]);
+    const size_t table_size = static_cast<size_t>(largest) + 1;
+    std::vector<int> leaf_of(table_size, -1);
     std::vector<uint32_t> symbols;
     std::vector<size_t> freq;
     MsvcHashOrder order;
@@ -310,8 +366,8 @@ void huffman_encode(const uint16_t* data, size_t n, BitWriter& out) {
     const uint8_t max_length = std::max<uint8_t>(heap.front().depth, 1);
     out.put(max_length, 8);
     std::vector<uint16_t> group_sizes;
-    std::vector<uint32_t> code_of(65536, 0);
-    std::vector<uint8_t> length_of(65536, 0);
+    std::vector<uint32_t> code_of(table_size, 0);
+    std::vector<uint8_t> length_of(table_size, 0);
     uint32_t eof_code = 0;
     uint8_t eof_length = 0;
     uint8_t prev_length = 0;
@@ -349,7 +405,9 @@ void huffman_encode(const uint16_t* data, size_t n, BitWriter& out) {
         else for (uint16_t v : group) out.put(v, symbol_bits);
         at += size;
     }
-    for (size_t i = 0; i < n; ++i) out.put(code_of[data[i]], length_of[data[i]]);
+    size_t payload_bits = 0;
+    for (int l = 0; l < eof_leaf; ++l) payload_bits += freq[l] * static_cast<size_t>(length_of[symbols[l]]);
+    out.put_codes(data, n, code_of.data(), length_of.data(), payload_bits);
     out.put(eof_code, eof_length);
 }
 
@@ -454,7 +512,9 @@ void write_huffman_or_golomb(const uint16_t* data, size_t n, BitWriter& out) {
     huffman_encode(data, n, huff);
     size_t best = huff.bit_size();
     int best_m = -1;
-    std::vector<uint32_t> hist(65536, 0);
+    uint16_t largest = 0;
+    for (size_t i = 0; i < n; ++i) largest = std::max(largest, data[i]);
+    std::vector<uint32_t> hist(static_cast<size_t>(largest) + 1, 0);
     std::vector<uint16_t> distinct;
     for (size_t i = 0; i < n; ++i)
         if (hist[data[i]]++ == 0) distinct.push_back(data[i]);
@@ -508,6 +568,81 @@ int host_threads() {
     return static_cast<int>(hc == 0 ? 1 : (hc > 16 ? 16 : hc));
 }
 
+// A small persistent pool: the workers are created on first use and sleep between calls (creating and joining 16
+// threads per call cost more than coding a 1080p frame's streams).  One parallel_for at a time (callers serialise on
+// `submit_`); the calling thread works too.
+class WorkerPool {
+public:
+    static WorkerPool& instance() {
+        static WorkerPool pool;
+        return pool;
+    }
+    void run(int n, int workers, const std::function<void(int)>& body) {
+        std::lock_guard<std::mutex> one_at_a_time(submit_);
+        ensure(workers - 1);
+        {
+            std::lock_guard<std::mutex> hold(lock_);
+            body_ = &body;
+            total_ = n;
+            next_.store(0);
+            pending_ = std::min<int>(workers - 1, static_cast<int>(threads_.size()));
+            active_limit_ = pending_;
+            ++generation_;
+        }
+        wake_.notify_all();
+        for (int i = next_.fetch_add(1); i < n; i = next_.fetch_add(1)) body(i);
+        std::unique_lock<std::mutex> hold(lock_);
+        done_.wait(hold, [&] { return pending_ == 0; });
+        body_ = nullptr;
+    }
+    ~WorkerPool() {
+        {
+            std::lock_guard<std::mutex> hold(lock_);
+            stop_ = true;
+            ++generation_;
+        }
+        wake_.notify_all();
+        for (auto& t : threads_) t.join();
+    }
+
+private:
+    void ensure(int count) {
+        while (static_cast<int>(threads_.size()) < count) {
+            const int id = static_cast<int>(threads_.size());
+            threads_.emplace_back([this, id] { loop(id); });
+        }
+    }
+    void loop(int id) {
+        unsigned long long seen = 0;
+        for (;;) {
+            const std::function<void(int)>* body = nullptr;
+            int total = 0;
+            {
+                std::unique_lock<std::mutex> hold(lock_);
+                wake_.wait(hold, [&] { return stop_ || generation_ != seen; });
+                if (stop_) return;
+                seen = generation_;
+                if (id >= active_limit_) continue;             // this call wants fewer workers
+                body = body_;
+                total = total_;
+            }
+            for (int i = next_.fetch_add(1); i < total; i = next_.fetch_add(1)) (*body)(i);
+            {
+                std::lock_guard<std::mutex> hold(lock_);
+                if (--pending_ == 0) done_.notify_one();
+            }
+        }
+    }
+    std::mutex submit_, lock_;
+    std::condition_variable wake_, done_;
+    std::vector<std::thread> threads_;
+    const std::function<void(int)>* body_ = nullptr;
+    std::atomic<int> next_{0};
+    int total_ = 0, pending_ = 0, active_limit_ = 0;
+    unsigned long long generation_ = 0;
+    bool stop_ = false;
+};
+
 template <class F>
 void parallel_for(int n, F&& body) {
     const int workers = std::min(host_threads(), n);
@@ -515,14 +650,8 @@ void parallel_for(int n, F&& body) {
         for (int i = 0; i < n; ++i) body(i);
         return;
     }
-    std::atomic<int> next{0};
-    std::vector<std::thread> pool;
-    pool.reserve(static_cast<size_t>(workers));
-    for (int w = 0; w < workers; ++w)
-        pool.emplace_back([&]() {
-            for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) body(i);
-        });
-    for (auto& t : pool) t.join();
+    const std::function<void(int)> fn = [&](int i) { body(i); };
+    WorkerPool::instance().run(n, workers, fn);
 }
 }  // namespace
 

@@ -17,6 +17,8 @@ class BitWriter {
 public:
     void put(uint64_t value, int width);            // MSB first; width 0..64
     void append(const BitWriter& other);
+    // put(code_of[s], length_of[s]) for every s in data[0..n), through a register accumulator (lengths 1..32)
+    void put_codes(const uint16_t* data, size_t n, const uint32_t* code_of, const uint8_t* length_of, size_t total_bits);
     size_t bit_size() const { return nbits_; }
     std::vector<uint8_t> bytes() const;             // zero-padded to a whole byte (BitBuffer::Save)
 private:
