@@ -743,12 +743,22 @@ Streams assemble_streams(int width, int height, int K, int block_size, const dou
                          static_cast<size_t>((height + block_size - 1) / block_size);
     s.lengths.resize(3 * tiles);
     s.codes.assign(static_cast<size_t>(6 * K), {});
-    // stream sizes first (one pass), then fill: no reallocation on multi-megabyte streams
+    // stream sizes first, then fill: no reallocation on multi-megabyte streams.  Step i of a channel holds one symbol
+    // per tile-channel with count > i: suffix sums of the histogram of counts.
     std::vector<size_t> sizes(static_cast<size_t>(3 * K), 0);
-    for (size_t o = 0; o < 3 * tiles; ++o) {
-        s.lengths[o] = counts[o];
-        const int ch = static_cast<int>(o % 3);
-        for (int i = 0; i < counts[o]; ++i) ++sizes[static_cast<size_t>(ch * K + i)];
+    {
+        std::vector<size_t> hist(static_cast<size_t>(3 * (K + 1)), 0);
+        for (size_t o = 0; o < 3 * tiles; ++o) {
+            s.lengths[o] = counts[o];
+            ++hist[(o % 3) * static_cast<size_t>(K + 1) + std::min<size_t>(counts[o], static_cast<size_t>(K))];
+        }
+        for (int ch = 0; ch < 3; ++ch) {
+            size_t above = 0;
+            for (int i = K - 1; i >= 0; --i) {
+                above += hist[static_cast<size_t>(ch) * (K + 1) + static_cast<size_t>(i + 1)];
+                sizes[static_cast<size_t>(ch * K + i)] = above;
+            }
+        }
     }
     for (int ch = 0; ch < 3; ++ch)
         for (int i = 0; i < K; ++i) {

@@ -61,6 +61,12 @@ struct mpc_context {
     uint16_t* d_base_f32 = nullptr;   // filter copies (mp_device.h)
     uint16_t* d_detail_f32 = nullptr;
     int* d_flag = nullptr;            // decode: set when a record indexes outside its dictionary
+    // grow-only device staging for the host-buffer entry points (mpc_encode_tiles / mpc_encode_image): allocating and
+    // freeing five buffers per call cost several times the encode itself
+    void* stage = nullptr;
+    size_t stage_bytes = 0;
+    void* host_stage = nullptr;       // pinned: records of mpc_encode_image on their way to the entropy stage
+    size_t host_stage_bytes = 0;
     // The pursuit of a call is cut into sub-batches that run on `pipes` internal streams, each with its own
     // workspace: the latency-bound bookkeeping kernels of one sub-batch (finish, update, bucket, fill) overlap
     // the machine-filling sweeps of the other.  Fork/join with events on the caller's stream: still no host
@@ -295,6 +301,8 @@ void mpc_context_destroy(mpc_context* c) {
         (void)hipFree(c->d_base_f32);
         (void)hipFree(c->d_detail_f32);
         (void)hipFree(c->d_flag);
+        (void)hipFree(c->stage);
+        if (c->host_stage) (void)hipHostFree(c->host_stage);
         for (auto& p : c->pipes) {
             if (p.mem) (void)hipFree(p.mem);
             if (p.stream) (void)hipStreamDestroy(p.stream);
@@ -403,36 +411,39 @@ mpc_status mpc_encode_tiles(mpc_context* c, const uint8_t* rgb, int width, int h
     const int tiles_x = (width + 7) / 8;
     const long long tiles = static_cast<long long>(tiles_x) * (tile_row_end - tile_row_begin);
     if (tiles <= 0) return fail(MPC_ERR_ARGUMENT, "empty stripe");
-    uint8_t* d_rgb = nullptr;
-    uint16_t* d_counts = nullptr;
-    mpc_basis_choice* d_choices = nullptr;
-    double* d_energy = nullptr;
-    uint32_t* d_swept = nullptr;
     const size_t img_bytes = row_stride * static_cast<size_t>(height);
+    auto up = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
+    const size_t n_tc = static_cast<size_t>(tiles) * 3;
+    const size_t off_counts = up(img_bytes), off_choices = off_counts + up(sizeof(uint16_t) * n_tc),
+                 off_energy = off_choices + up(sizeof(mpc_basis_choice) * n_tc * c->K), off_swept = off_energy + up(sizeof(double) * n_tc),
+                 total = off_swept + up(sizeof(uint32_t) * n_tc);
+    if (total > c->stage_bytes) {
+        if (c->stage) (void)hipFree(c->stage);
+        c->stage = nullptr;
+        c->stage_bytes = 0;
+        const hipError_t ea = hipMalloc(&c->stage, total);
+        if (ea != hipSuccess) return fail(MPC_ERR_ALLOC, "staging of %zu bytes: %s", total, hipGetErrorString(ea));
+        c->stage_bytes = total;
+    }
+    char* base = static_cast<char*>(c->stage);
+    uint8_t* d_rgb = reinterpret_cast<uint8_t*>(base);
+    uint16_t* d_counts = reinterpret_cast<uint16_t*>(base + off_counts);
+    mpc_basis_choice* d_choices = reinterpret_cast<mpc_basis_choice*>(base + off_choices);
+    double* d_energy = reinterpret_cast<double*>(base + off_energy);
+    uint32_t* d_swept = reinterpret_cast<uint32_t*>(base + off_swept);
     mpc_status st = MPC_OK;
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_rgb), img_bytes);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_counts), sizeof(uint16_t) * tiles * 3);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_choices), sizeof(mpc_basis_choice) * tiles * 3 * c->K);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_energy), sizeof(double) * tiles * 3);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_swept), sizeof(uint32_t) * tiles * 3);
-    if (e == hipSuccess) e = hipMemcpy(d_rgb, rgb, img_bytes, hipMemcpyHostToDevice);
+    hipError_t e = hipMemcpy(d_rgb, rgb, img_bytes, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
         st = mpc_encode_tiles_device(c, d_rgb, width, height, row_stride, tile_row_begin, tile_row_end, quant, d_counts,
                                      d_choices, d_energy, d_swept, 0, nullptr);
         if (st == MPC_OK) {
             e = hipDeviceSynchronize();
-            if (e == hipSuccess) e = hipMemcpy(counts, d_counts, sizeof(uint16_t) * tiles * 3, hipMemcpyDeviceToHost);
-            if (e == hipSuccess)
-                e = hipMemcpy(choices, d_choices, sizeof(mpc_basis_choice) * tiles * 3 * c->K, hipMemcpyDeviceToHost);
-            if (e == hipSuccess && energy) e = hipMemcpy(energy, d_energy, sizeof(double) * tiles * 3, hipMemcpyDeviceToHost);
-            if (e == hipSuccess && swept) e = hipMemcpy(swept, d_swept, sizeof(uint32_t) * tiles * 3, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(counts, d_counts, sizeof(uint16_t) * n_tc, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(choices, d_choices, sizeof(mpc_basis_choice) * n_tc * c->K, hipMemcpyDeviceToHost);
+            if (e == hipSuccess && energy) e = hipMemcpy(energy, d_energy, sizeof(double) * n_tc, hipMemcpyDeviceToHost);
+            if (e == hipSuccess && swept) e = hipMemcpy(swept, d_swept, sizeof(uint32_t) * n_tc, hipMemcpyDeviceToHost);
         }
     }
-    (void)hipFree(d_rgb);
-    (void)hipFree(d_counts);
-    (void)hipFree(d_choices);
-    (void)hipFree(d_energy);
-    (void)hipFree(d_swept);
     if (st != MPC_OK) return st;
     if (e != hipSuccess) return fail(MPC_ERR_HIP, "HIP failure: %s", hipGetErrorString(e));
     return MPC_OK;
@@ -707,13 +718,25 @@ mpc_status mpc_encode_image(mpc_context* c, const uint8_t* rgb, int width, int h
     if (c->device < 0) return fail(MPC_ERR_NO_DEVICE, "context was created without a device; there is no CPU fallback");
     const int tiles_x = (width + 7) / 8, tiles_y = (height + 7) / 8;
     const size_t tiles = static_cast<size_t>(tiles_x) * tiles_y;
-    std::vector<uint16_t> counts(tiles * 3);
-    std::vector<mpc_basis_choice> choices(tiles * 3 * c->K);
-    mpc_status st = mpc_encode_tiles(c, rgb, width, height, static_cast<size_t>(3) * width, 0, tiles_y, quant, counts.data(),
-                                     choices.data(), nullptr, nullptr);
+    // the records come back into pinned host memory kept by the context (a fresh 100 MB vector per call costs more in
+    // page faults than the device spends encoding)
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t counts_bytes = (sizeof(uint16_t) * tiles * 3 + 255) & ~static_cast<size_t>(255);
+    const size_t need = counts_bytes + sizeof(mpc_basis_choice) * tiles * 3 * c->K;
+    if (need > c->host_stage_bytes) {
+        if (c->host_stage) (void)hipHostFree(c->host_stage);
+        c->host_stage = nullptr;
+        c->host_stage_bytes = 0;
+        const hipError_t e = hipHostMalloc(&c->host_stage, need, hipHostMallocDefault);
+        if (e != hipSuccess) return fail(MPC_ERR_ALLOC, "pinned staging of %zu bytes: %s", need, hipGetErrorString(e));
+        c->host_stage_bytes = need;
+    }
+    uint16_t* counts = static_cast<uint16_t*>(c->host_stage);
+    mpc_basis_choice* choices = reinterpret_cast<mpc_basis_choice*>(static_cast<char*>(c->host_stage) + counts_bytes);
+    mpc_status st = mpc_encode_tiles(c, rgb, width, height, static_cast<size_t>(3) * width, 0, tiles_y, quant, counts, choices,
+                                     nullptr, nullptr);
     if (st != MPC_OK) return st;
-    return mpc_assemble_streams(width, height, c->K, c->block_size, quant ? quant : c->quant.data(), counts.data(),
-                                choices.data(), bytes, nbytes);
+    return mpc_assemble_streams(width, height, c->K, c->block_size, quant ? quant : c->quant.data(), counts, choices, bytes, nbytes);
 }
 
 // FromCoeffsDynamic + RGBFromYUV for whole tiles on the device
