@@ -690,6 +690,64 @@ std::vector<uint8_t> write_compressed(const Streams& s) {
     return out.bytes();
 }
 
+// assemble_streams + write_compressed in one go, without materialising the 6K streams of a frame (hundreds of MB of
+// freshly faulted pages at K = 32): one job per (channel, step) gathers its two streams into buffers the worker thread
+// keeps between calls and codes them straight into its part of the container.  Same bytes as the two-step route.
+std::vector<uint8_t> encode_records(int width, int height, int K, int block_size, const double* quant, const uint16_t* counts,
+                                    const uint32_t* choices) {
+    const size_t tiles = static_cast<size_t>((width + block_size - 1) / block_size) *
+                         static_cast<size_t>((height + block_size - 1) / block_size);
+    BitWriter out;
+    out.put(kMagic, 32);
+    out.put(static_cast<uint32_t>(width), 32);
+    out.put(static_cast<uint32_t>(height), 32);
+    out.put(static_cast<uint8_t>(K), 8);
+    out.put(static_cast<uint8_t>(block_size), 8);
+    for (int ch = 0; ch < 3; ++ch)
+        for (int i = 0; i < K; ++i) out.put(static_cast<uint16_t>(quant[ch * K + i]), 16);    // :420 u16 of an integral double
+    std::vector<BitWriter> parts(static_cast<size_t>(6 * K + 1));
+    auto code_stream = [](const std::vector<uint16_t>& stream, bool dc, std::vector<uint16_t>& scratch, BitWriter& w) {
+        const std::vector<uint16_t>* src = &stream;
+        if (dc) {
+            scratch = dc_difference(stream);
+            src = &scratch;
+        }
+        const std::vector<uint16_t> packed = rle_encode(src->data(), src->size());
+        if (packed.size() + 4 < src->size()) {                  // :450
+            w.put(1, 1);
+            w.put(static_cast<uint32_t>(packed.size()), 32);
+            write_huffman_or_golomb(packed.data(), packed.size(), w);
+        } else {
+            w.put(0, 1);
+            write_huffman_or_golomb(src->data(), src->size(), w);
+        }
+    };
+    // the big jobs first: step 0 of every channel holds every tile-channel, later steps fewer
+    parallel_for(3 * K + 1, [&](int job) {
+        if (job == 3 * K) {
+            write_huffman_or_golomb(counts, 3 * tiles, parts[0]);                              // the lengths stream
+            return;
+        }
+        const int i = job / 3, ch = job - 3 * i;                 // job order: (step 0: Y U V), (step 1: Y U V), ...
+        thread_local std::vector<uint16_t> d, c, scratch;
+        d.clear();
+        c.clear();
+        for (size_t t = 0; t < tiles; ++t) {
+            const size_t o = 3 * t + static_cast<size_t>(ch);
+            if (counts[o] > i) {
+                const uint32_t rec = choices[o * K + i];
+                d.push_back(static_cast<uint16_t>(rec & 0xFFFFu));
+                c.push_back(static_cast<uint16_t>(rec >> 16));
+            }
+        }
+        const int index = 2 * K * ch + 2 * i;                    // codes[index] = deltaId, [index + 1] = intCoeff
+        code_stream(d, false, scratch, parts[static_cast<size_t>(index + 1)]);
+        code_stream(c, i == 0, scratch, parts[static_cast<size_t>(index + 2)]);   // DC: the step-0 coefficients (:428-446)
+    });
+    for (const BitWriter& w : parts) out.append(w);
+    return out.bytes();
+}
+
 bool read_compressed(const uint8_t* bytes, size_t nbytes, Streams& s) {
     BitReader in(bytes, nbytes);
     if (static_cast<uint32_t>(in.get(32)) != kMagic) return false;

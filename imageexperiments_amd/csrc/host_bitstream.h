@@ -71,6 +71,10 @@ bool read_compressed(const uint8_t* bytes, size_t nbytes, Streams& out);
 Streams assemble_streams(int width, int height, int K, int block_size, const double* quant /*[3*K]*/,
                          const uint16_t* counts, const uint32_t* choices);
 
+// assemble_streams + write_compressed without the intermediate streams (what mpc_assemble_streams / mpc_encode_image use)
+std::vector<uint8_t> encode_records(int width, int height, int K, int block_size, const double* quant /*[3*K]*/,
+                                    const uint16_t* counts, const uint32_t* choices);
+
 // Inverse of assemble_streams: per-tile records in the reference's visiting order.  counts[3*tiles],
 // choices[3*tiles*K] (deltaId | intCoeff << 16, zero beyond count).  false = streams inconsistent with `lengths`.
 bool disassemble_streams(const Streams& s, std::vector<uint16_t>& counts, std::vector<uint32_t>& choices);

@@ -630,9 +630,8 @@ mpc_status mpc_assemble_streams(int width, int height, int K, int block_size, co
                                 const uint16_t* counts, const mpc_basis_choice* choices, uint8_t** bytes, size_t* nbytes) {
     if (!quant || !counts || !choices || !bytes || !nbytes || K < 1 || K > MPC_MAX_K || block_size < 1 || width < 1 || height < 1)
         return fail(MPC_ERR_ARGUMENT, "bad argument");
-    const mpc::Streams s = mpc::assemble_streams(width, height, K, block_size, quant, counts,
-                                                 reinterpret_cast<const uint32_t*>(choices));
-    *bytes = give_bytes(mpc::write_compressed(s), nbytes);
+    *bytes = give_bytes(mpc::encode_records(width, height, K, block_size, quant, counts, reinterpret_cast<const uint32_t*>(choices)),
+                        nbytes);
     return *bytes ? MPC_OK : fail(MPC_ERR_ALLOC, "out of memory");
 }
 
