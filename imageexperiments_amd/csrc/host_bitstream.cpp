@@ -113,6 +113,20 @@ uint64_t BitReader::get(int width) {
     return v;
 }
 
+uint32_t BitReader::peek32() const {
+    const size_t byte = pos_ >> 3;
+    const int off = static_cast<int>(pos_ & 7);
+    const size_t nbytes = (nbits_ + 7) >> 3;
+    uint64_t window = 0;                                        // 5 bytes cover 32 bits at any bit offset
+    if (byte + 5 <= nbytes) {
+        window = (static_cast<uint64_t>(p_[byte]) << 32) | (static_cast<uint64_t>(p_[byte + 1]) << 24) |
+                 (static_cast<uint64_t>(p_[byte + 2]) << 16) | (static_cast<uint64_t>(p_[byte + 3]) << 8) | p_[byte + 4];
+    } else {
+        for (int k = 0; k < 5; ++k) window = (window << 8) | (byte + k < nbytes ? p_[byte + k] : 0u);
+    }
+    return static_cast<uint32_t>(window >> (8 - off));
+}
+
 namespace {
 
 inline uint32_t bit_width(uint32_t v) { return v ? 32u - static_cast<uint32_t>(__builtin_clz(v)) : 0u; }
@@ -446,20 +460,62 @@ bool huffman_decode(BitReader& in, std::vector<uint16_t>& out) {
         index += counts[l - 1];
         prev = l;
     }
-    uint32_t acc = 0;
-    int bits = 0;
-    while (in.remaining() > 0) {
-        acc = (acc << 1) | static_cast<uint32_t>(in.get(1));
-        ++bits;
-        if (bits <= max_length && counts[bits - 1] && acc >= first_code[bits] && acc - first_code[bits] < counts[bits - 1]) {
-            const uint32_t entry = first_index[bits] + (acc - first_code[bits]);
-            if (entry == static_cast<uint32_t>(total) - 1u) return true;
-            out.push_back(table[entry]);
-            acc = 0;
-            bits = 0;
+    // The reference shifts bits in one at a time and takes the first length at which the accumulated value is a code
+    // of that length.  Same decisions here from a 32-bit look-ahead: codes of up to kLutBits bits through a table
+    // (filled shortest length first, so an over-subscribed table still resolves to the first match), longer ones by
+    // the reference's test per length.
+    if (max_length > 32) {                                      // no encoder writes this; keep the literal bit-by-bit walk
+        uint64_t acc = 0;
+        int bits = 0;
+        while (in.remaining() > 0) {
+            acc = (acc << 1) | in.get(1);
+            ++bits;
+            if (bits <= 32 && counts[bits - 1] && acc >= first_code[bits] && acc - first_code[bits] < counts[bits - 1]) {
+                const uint32_t entry = first_index[bits] + static_cast<uint32_t>(acc - first_code[bits]);
+                if (entry == static_cast<uint32_t>(total) - 1u) return true;
+                out.push_back(table[entry]);
+                acc = 0;
+                bits = 0;
+            }
+        }
+        return false;
+    }
+    constexpr int kLutBits = 11;
+    std::vector<uint32_t> lut(static_cast<size_t>(1) << kLutBits, 0);           // (entry << 5) | length, 0 = no short code
+    for (int l = 1; l <= std::min(max_length, kLutBits); ++l) {
+        for (uint32_t k = 0; k < counts[l - 1]; ++k) {
+            const uint64_t value = static_cast<uint64_t>(first_code[l]) + k;
+            if (value >> l) break;                                              // not an l-bit number: can never match
+            const uint32_t lo = static_cast<uint32_t>(value) << (kLutBits - l);
+            for (uint32_t fill = 0; fill < (1u << (kLutBits - l)); ++fill)
+                if (lut[lo + fill] == 0) lut[lo + fill] = ((first_index[l] + k) << 5) | static_cast<uint32_t>(l);
         }
     }
-    return false;
+    for (;;) {
+        const size_t left = in.remaining();
+        if (left == 0) return false;
+        const uint32_t window = in.peek32();
+        uint32_t entry = 0;
+        int used = 0;
+        const uint32_t hit = lut[window >> (32 - kLutBits)];
+        if (hit != 0 && (hit & 31u) <= left) {
+            entry = hit >> 5;
+            used = static_cast<int>(hit & 31u);
+        } else {
+            for (int l = (hit != 0 ? 1 : kLutBits + 1); l <= max_length && static_cast<size_t>(l) <= left; ++l) {
+                const uint32_t acc = window >> (32 - l);
+                if (counts[l - 1] && acc >= first_code[l] && acc - first_code[l] < counts[l - 1]) {
+                    entry = first_index[l] + (acc - first_code[l]);
+                    used = l;
+                    break;
+                }
+            }
+            if (used == 0) return false;                        // the reference reads on to the end of the data and fails
+        }
+        in.skip(static_cast<size_t>(used));
+        if (entry == static_cast<uint32_t>(total) - 1u) return true;
+        out.push_back(table[entry]);
+    }
 }
 
 // Huffman.cpp:246-310
@@ -764,6 +820,22 @@ bool read_compressed(const uint8_t* bytes, size_t nbytes, Streams& s) {
     s.lengths.clear();
     if (!read_huffman_or_golomb(in, 3 * tiles, s.lengths)) return false;
     s.codes.assign(static_cast<size_t>(6 * K), {});
+    // length of an un-packed stream = tile-channels of its layer with more than `depth` atoms (:680-685): suffix sums
+    // of the histogram of lengths, once for all 6K streams
+    std::vector<size_t> expect_of(static_cast<size_t>(3 * K), 0);
+    {
+        std::vector<size_t> hist(static_cast<size_t>(3) * 65536, 0);
+        for (size_t t = 0; t < s.lengths.size() / 3; ++t)
+            for (size_t layer = 0; layer < 3; ++layer) ++hist[layer * 65536 + s.lengths[3 * t + layer]];
+        for (size_t layer = 0; layer < 3; ++layer) {
+            size_t above = 0;
+            for (int v = 65535; v > K; --v) above += hist[layer * 65536 + static_cast<size_t>(v)];
+            for (int depth = K - 1; depth >= 0; --depth) {
+                above += hist[layer * 65536 + static_cast<size_t>(depth + 1)];
+                expect_of[layer * static_cast<size_t>(K) + static_cast<size_t>(depth)] = above;
+            }
+        }
+    }
     for (int i = 0; i < 6 * K; ++i) {
         if (in.get(1) == 1) {
             const size_t packed_len = static_cast<size_t>(in.get(32));
@@ -772,10 +844,7 @@ bool read_compressed(const uint8_t* bytes, size_t nbytes, Streams& s) {
             s.codes[i] = rle_decode(packed.data(), packed.size());
         } else {
             const size_t layer = static_cast<size_t>(i / 2) / K, depth = static_cast<size_t>(i / 2) % K;
-            size_t expect = 0;                                   // :680-685 length implied by `lengths`
-            for (size_t t = 0; t < s.lengths.size() / 3; ++t)
-                if (s.lengths[3 * t + layer] > depth) ++expect;
-            if (!read_huffman_or_golomb(in, expect, s.codes[i])) return false;
+            if (!read_huffman_or_golomb(in, expect_of[layer * static_cast<size_t>(K) + depth], s.codes[i])) return false;
         }
     }
     for (int idx : {1, 2 * K + 1, 4 * K + 1}) {                  // :690-705
@@ -840,16 +909,15 @@ Streams assemble_streams(int width, int height, int K, int block_size, const dou
     return s;
 }
 
-bool disassemble_streams(const Streams& s, std::vector<uint16_t>& counts, std::vector<uint32_t>& choices) {
+bool disassemble_streams(const Streams& s, uint16_t* counts, uint32_t* choices) {
     const int K = s.K;
     const size_t n = s.lengths.size();
-    counts.assign(s.lengths.begin(), s.lengths.end());
-    choices.assign(n * static_cast<size_t>(K), 0);
     std::vector<size_t> cursor(static_cast<size_t>(3 * K), 0);
     for (size_t o = 0; o < n; ++o) {
         const int ch = static_cast<int>(o % 3);
         const int count = s.lengths[o];
         if (count > K) return false;
+        counts[o] = s.lengths[o];
         for (int i = 0; i < count; ++i) {
             const std::vector<uint16_t>& d = s.codes[2 * K * ch + 2 * i];
             const std::vector<uint16_t>& c = s.codes[2 * K * ch + 2 * i + 1];
@@ -860,6 +928,12 @@ bool disassemble_streams(const Streams& s, std::vector<uint16_t>& counts, std::v
         }
     }
     return true;
+}
+
+bool disassemble_streams(const Streams& s, std::vector<uint16_t>& counts, std::vector<uint32_t>& choices) {
+    counts.assign(s.lengths.size(), 0);
+    choices.assign(s.lengths.size() * static_cast<size_t>(s.K), 0);
+    return disassemble_streams(s, counts.data(), choices.data());
 }
 
 }  // namespace mpc

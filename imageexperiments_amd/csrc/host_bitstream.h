@@ -32,6 +32,9 @@ public:
     // BitBuffer::ReadBits: the width is clipped to what remains; past the end it returns 0
     uint64_t get(int width);
     size_t remaining() const { return nbits_ - pos_; }
+    // the next 32 bits left-aligned (zero beyond the end), without consuming them; skip() consumes
+    uint32_t peek32() const;
+    void skip(size_t bits) { pos_ += bits; }
 private:
     const uint8_t* p_;
     size_t nbits_;
@@ -78,5 +81,7 @@ std::vector<uint8_t> encode_records(int width, int height, int K, int block_size
 // Inverse of assemble_streams: per-tile records in the reference's visiting order.  counts[3*tiles],
 // choices[3*tiles*K] (deltaId | intCoeff << 16, zero beyond count).  false = streams inconsistent with `lengths`.
 bool disassemble_streams(const Streams& s, std::vector<uint16_t>& counts, std::vector<uint32_t>& choices);
+// same into caller-provided storage (3*tiles and 3*tiles*K elements); entries beyond a count are left untouched
+bool disassemble_streams(const Streams& s, uint16_t* counts, uint32_t* choices);
 
 }  // namespace mpc

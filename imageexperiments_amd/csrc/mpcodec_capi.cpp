@@ -773,22 +773,40 @@ mpc_status mpc_decode_image(const mpc_context* cc, const uint8_t* bytes, size_t 
     if (!mpc::read_compressed(bytes, nbytes, s)) return fail(MPC_ERR_BITSTREAM, "Invalid input data");
     mpc_context* c = const_cast<mpc_context*>(cc);
     if (c && c->device >= 0 && c->K == s.K && s.block_size == 8) {
-        std::vector<uint16_t> counts;
-        std::vector<uint32_t> choices;
+        // records via the context's pinned host buffer and device staging area (grow-only, shared with the encoder)
+        HIP_TRY(hipSetDevice(c->device));
+        const size_t n_tc = s.lengths.size();
+        auto up = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
+        const size_t counts_bytes = up(sizeof(uint16_t) * n_tc), choices_bytes = up(sizeof(uint32_t) * n_tc * s.K);
+        const size_t px = static_cast<size_t>(s.width) * s.height * 3;
+        if (counts_bytes + choices_bytes > c->host_stage_bytes) {
+            if (c->host_stage) (void)hipHostFree(c->host_stage);
+            c->host_stage = nullptr;
+            c->host_stage_bytes = 0;
+            const hipError_t ea = hipHostMalloc(&c->host_stage, counts_bytes + choices_bytes, hipHostMallocDefault);
+            if (ea != hipSuccess) return fail(MPC_ERR_ALLOC, "pinned staging: %s", hipGetErrorString(ea));
+            c->host_stage_bytes = counts_bytes + choices_bytes;
+        }
+        if (counts_bytes + choices_bytes + up(px) > c->stage_bytes) {
+            if (c->stage) (void)hipFree(c->stage);
+            c->stage = nullptr;
+            c->stage_bytes = 0;
+            const hipError_t ea = hipMalloc(&c->stage, counts_bytes + choices_bytes + up(px));
+            if (ea != hipSuccess) return fail(MPC_ERR_ALLOC, "device staging: %s", hipGetErrorString(ea));
+            c->stage_bytes = counts_bytes + choices_bytes + up(px);
+        }
+        uint16_t* counts = static_cast<uint16_t*>(c->host_stage);
+        uint32_t* choices = reinterpret_cast<uint32_t*>(static_cast<char*>(c->host_stage) + counts_bytes);
         if (!mpc::disassemble_streams(s, counts, choices)) return fail(MPC_ERR_BITSTREAM, "Invalid bitstream");
         std::vector<double> q(3 * static_cast<size_t>(s.K));
         for (int ch = 0; ch < 3; ++ch)
             for (int i = 0; i < s.K; ++i) q[ch * s.K + i] = static_cast<double>(s.quant[ch][i]);
-        HIP_TRY(hipSetDevice(c->device));
-        uint16_t* d_counts = nullptr;
-        uint32_t* d_choices = nullptr;
-        uint8_t* d_rgb = nullptr;
-        const size_t px = static_cast<size_t>(s.width) * s.height * 3;
-        hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_counts), counts.size() * 2);
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_choices), choices.size() * 4);
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_rgb), px);
-        if (e == hipSuccess) e = hipMemcpy(d_counts, counts.data(), counts.size() * 2, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(d_choices, choices.data(), choices.size() * 4, hipMemcpyHostToDevice);
+        char* dbase = static_cast<char*>(c->stage);
+        uint16_t* d_counts = reinterpret_cast<uint16_t*>(dbase);
+        uint32_t* d_choices = reinterpret_cast<uint32_t*>(dbase + counts_bytes);
+        uint8_t* d_rgb = reinterpret_cast<uint8_t*>(dbase + counts_bytes + choices_bytes);
+        hipError_t e = hipMemcpy(d_counts, counts, sizeof(uint16_t) * n_tc, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(d_choices, choices, sizeof(uint32_t) * n_tc * s.K, hipMemcpyHostToDevice);
         mpc_status st = MPC_OK;
         int flag = 0;
         uint8_t* out = nullptr;
@@ -804,9 +822,6 @@ mpc_status mpc_decode_image(const mpc_context* cc, const uint8_t* bytes, size_t 
             }
             if (e == hipSuccess) e = hipMemcpy(c->d_quant, c->quant.data(), c->quant.size() * sizeof(double), hipMemcpyHostToDevice);
         }
-        (void)hipFree(d_counts);
-        (void)hipFree(d_choices);
-        (void)hipFree(d_rgb);
         if (st != MPC_OK) { std::free(out); return st; }
         if (e != hipSuccess) { std::free(out); return fail(MPC_ERR_HIP, "HIP failure: %s", hipGetErrorString(e)); }
         if (!out) return fail(MPC_ERR_ALLOC, "out of memory");
