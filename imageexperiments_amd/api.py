@@ -98,6 +98,7 @@ def _bind_bitstream(L):
     L.mpc_rle_encode.argtypes = [_u16p, C.c_size_t, C.POINTER(_u16p), C.POINTER(C.c_size_t)]
     L.mpc_rle_decode.argtypes = [_u16p, C.c_size_t, C.POINTER(_u16p), C.POINTER(C.c_size_t)]
     L.mpc_encode_image.argtypes = [vp, _u8p, C.c_int, C.c_int, _dp, C.POINTER(_u8p), C.POINTER(C.c_size_t)]
+    L.mpc_encode_images.argtypes = [vp, C.POINTER(_u8p), C.c_int, C.c_int, C.c_int, _dp, C.POINTER(_u8p), C.POINTER(C.c_size_t)]
     L.mpc_decode_tiles_device.argtypes = [vp, vp, vp, _dp, C.c_int, C.c_int, vp, vp]
     L.mpc_decode_image.argtypes = [vp, _u8p, C.c_size_t, C.POINTER(_u8p), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.mpc_psnr.argtypes = [_u8p, _u8p, C.c_int, C.c_int]
@@ -358,6 +359,24 @@ class CompressionContext:
         out, n = _u8p(), C.c_size_t(0)
         _check(self.L.mpc_encode_image(self.h, rgb.ctypes.data_as(_u8p), W, H, qp, C.byref(out), C.byref(n)))
         return _take_bytes(self.L, out, n)
+
+    def encode_images(self, frames, quant=None):
+        """encodeImage for a sequence of equally sized frames, host entropy stage of frame n overlapped with the device
+        encode of frame n+1 (mpc_encode_images).  Returns a list of bytes objects."""
+        frames = [np.ascontiguousarray(f, np.uint8) for f in frames]
+        H, W = frames[0].shape[:2]
+        if any(f.shape[:2] != (H, W) for f in frames):
+            raise ValueError("frames must have the same size")
+        qp = None
+        if quant is not None:
+            quant = np.ascontiguousarray(quant, np.float64).reshape(3, self.K)
+            qp = quant.ctypes.data_as(_dp)
+        n = len(frames)
+        ptrs = (_u8p * n)(*[f.ctypes.data_as(_u8p) for f in frames])
+        outs = (_u8p * n)()
+        sizes = (C.c_size_t * n)()
+        _check(self.L.mpc_encode_images(self.h, ptrs, n, W, H, qp, outs, sizes))
+        return [_take_bytes(self.L, outs[i], C.c_size_t(sizes[i])) for i in range(n)]
 
     def calc_mp(self, channel, vectors, quant_k=None):
         """matching::CalcMPDynamic (MatchingPursuit.h:22) on the device for vectors[n,64].

@@ -13,6 +13,7 @@
 #include <new>
 #include <utility>
 #include <stdexcept>
+#include <future>
 #include <vector>
 
 #include "host_bitstream.h"
@@ -736,6 +737,68 @@ mpc_status mpc_encode_image(mpc_context* c, const uint8_t* rgb, int width, int h
                                      nullptr, nullptr);
     if (st != MPC_OK) return st;
     return mpc_assemble_streams(width, height, c->K, c->block_size, quant ? quant : c->quant.data(), counts, choices, bytes, nbytes);
+}
+
+mpc_status mpc_encode_images(mpc_context* c, const uint8_t* const* rgb_frames, int n_frames, int width, int height,
+                             const double* quant, uint8_t** bytes, size_t* nbytes) {
+    if (!c || !rgb_frames || !bytes || !nbytes || n_frames < 1) return fail(MPC_ERR_ARGUMENT, "bad argument");
+    if (c->device < 0) return fail(MPC_ERR_NO_DEVICE, "context was created without a device; there is no CPU fallback");
+    for (int f = 0; f < n_frames; ++f) {
+        if (!rgb_frames[f]) return fail(MPC_ERR_ARGUMENT, "null frame");
+        bytes[f] = nullptr;
+        nbytes[f] = 0;
+    }
+    const int tiles_y = (height + 7) / 8;
+    const size_t tiles = static_cast<size_t>((width + 7) / 8) * tiles_y;
+    HIP_TRY(hipSetDevice(c->device));
+    // two pinned record buffers: the entropy stage reads one while the device fills the other
+    const size_t counts_bytes = (sizeof(uint16_t) * tiles * 3 + 255) & ~static_cast<size_t>(255);
+    const size_t slot_bytes = counts_bytes + ((sizeof(mpc_basis_choice) * tiles * 3 * c->K + 255) & ~static_cast<size_t>(255));
+    if (2 * slot_bytes > c->host_stage_bytes) {
+        if (c->host_stage) (void)hipHostFree(c->host_stage);
+        c->host_stage = nullptr;
+        c->host_stage_bytes = 0;
+        const hipError_t e = hipHostMalloc(&c->host_stage, 2 * slot_bytes, hipHostMallocDefault);
+        if (e != hipSuccess) return fail(MPC_ERR_ALLOC, "pinned staging of %zu bytes: %s", 2 * slot_bytes, hipGetErrorString(e));
+        c->host_stage_bytes = 2 * slot_bytes;
+    }
+    const double* q = quant ? quant : c->quant.data();
+    struct Pending {
+        std::future<std::vector<uint8_t>> result;
+        int frame = -1;
+    } pending[2];
+    mpc_status st = MPC_OK;
+    auto collect = [&](Pending& p) {
+        if (p.frame < 0) return;
+        std::vector<uint8_t> blob = p.result.get();
+        if (st == MPC_OK) {
+            bytes[p.frame] = give_bytes(blob, &nbytes[p.frame]);
+            if (!bytes[p.frame]) st = fail(MPC_ERR_ALLOC, "out of memory");
+        }
+        p.frame = -1;
+    };
+    for (int f = 0; f < n_frames && st == MPC_OK; ++f) {
+        Pending& slot = pending[f & 1];
+        collect(slot);                                            // frame f-2 is done with this buffer
+        if (st != MPC_OK) break;
+        char* base = static_cast<char*>(c->host_stage) + static_cast<size_t>(f & 1) * slot_bytes;
+        uint16_t* counts = reinterpret_cast<uint16_t*>(base);
+        mpc_basis_choice* choices = reinterpret_cast<mpc_basis_choice*>(base + counts_bytes);
+        st = mpc_encode_tiles(c, rgb_frames[f], width, height, static_cast<size_t>(3) * width, 0, tiles_y, quant, counts, choices,
+                              nullptr, nullptr);
+        if (st != MPC_OK) break;
+        const int K = c->K, bs = c->block_size;
+        slot.frame = f;
+        slot.result = std::async(std::launch::async, [=] {
+            return mpc::encode_records(width, height, K, bs, q, counts, reinterpret_cast<const uint32_t*>(choices));
+        });
+    }
+    collect(pending[0]);
+    collect(pending[1]);
+    if (st != MPC_OK) {
+        for (int f = 0; f < n_frames; ++f) { std::free(bytes[f]); bytes[f] = nullptr; nbytes[f] = 0; }
+    }
+    return st;
 }
 
 // FromCoeffsDynamic + RGBFromYUV for whole tiles on the device

@@ -24,6 +24,7 @@
  *   mpc_write_compressed      compressed::writeCompressed (static)        CompressedImage.cpp:403
  *   mpc_read_compressed       compressed::readCompressed                  CompressedImage.cpp:635
  *   mpc_encode_image          compressed::encodeImage                     CompressedImage.h:59
+ *   mpc_encode_images         (same, a sequence of frames, host and device stages overlapped)
  *   mpc_decode_image          compressed::decodeImage                     CompressedImage.h:75
  *   mpc_decode_tiles_device   matching::FromCoeffsDynamic per tile        MatchingPursuit.h:25, CompressedImage.cpp:797-831
  *   mpc_psnr                  compressed::calculatePSNR                   CompressedImage.h:57
@@ -184,6 +185,13 @@ mpc_status mpc_rle_decode(const uint16_t* data, size_t n, uint16_t** out, size_t
  * tables.  Tile encode on the device, entropy stage on the host. */
 mpc_status mpc_encode_image(mpc_context* ctx, const uint8_t* rgb, int width, int height, const double* quant,
                             uint8_t** bytes, size_t* nbytes);
+
+/* The same for a sequence of equally sized frames (what Compression.cpp does per input file, :117/:166), pipelined: the
+ * host entropy stage of frame n runs while the device encodes frame n+1.  bytes[i] / nbytes[i] receive frame i's
+ * container (each to be released with mpc_free); byte-identical to n calls of mpc_encode_image.  On failure nothing is
+ * returned. */
+mpc_status mpc_encode_images(mpc_context* ctx, const uint8_t* const* rgb_frames, int n_frames, int width, int height,
+                             const double* quant, uint8_t** bytes, size_t* nbytes);
 
 /* matching::FromCoeffsDynamic (MatchingPursuit.h:25) + img::RGBFromYUV for every tile of a frame on the device:
  * records in the reference's order (tile t = tx*tiles_y + ty, as mpc_encode_tiles returns them for the whole

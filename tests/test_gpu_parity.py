@@ -396,3 +396,16 @@ def test_filter_equals_exact_sweep_on_a_whole_frame(gpu, oracle, monkeypatch):
         assert (a[1]["deltaId"] == b[1]["deltaId"]).all() and (a[1]["intCoeff"] == b[1]["intCoeff"]).all()
         assert (a[2].view(np.uint64) == b[2].view(np.uint64)).all()
         assert (a[3] == b[3]).all()
+
+
+def test_pipelined_frames_equal_single_frame_calls(gpu, oracle):
+    """mpc_encode_images overlaps the host entropy stage with the next frame's device encode: same bytes, frame by frame"""
+    import imageexperiments_amd as ia
+    ctx = ia.create_compression_context(8, 8, 3.5, device=0)
+    frames = [oracle.synth_frame(320, 200, 500 + f) for f in range(5)]
+    singles = [bytes(ctx.encode_image(f)) for f in frames]
+    batch = [bytes(b) for b in ctx.encode_images(frames)]
+    assert batch == singles
+    octx = oracle.OracleContext(8, 8, 3.5)
+    assert batch[3] == bytes(octx.encode_image(frames[3]))
+    ctx.close()
