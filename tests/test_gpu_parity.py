@@ -409,3 +409,13 @@ def test_pipelined_frames_equal_single_frame_calls(gpu, oracle):
     octx = oracle.OracleContext(8, 8, 3.5)
     assert batch[3] == bytes(octx.encode_image(frames[3]))
     ctx.close()
+
+
+def test_natural_image_crops_bytes_equal_oracle(gpu, oracle, ctx32, octx32, mn_bytes):
+    """natural content (crops of the reference's own photograph, decoded from its .mn fixture): the filter sees real
+    edges, textures and flat sky instead of synthetic gradients; bytes must equal the oracle's"""
+    import imageexperiments_amd as ia
+    photo = ia.decode_image(mn_bytes, ctx32)
+    for (x0, y0, w, h) in ((1000, 800, 256, 192), (3000, 2000, 320, 160), (0, 0, 200, 120), (4600, 3100, 328, 164)):
+        crop = np.ascontiguousarray(photo[y0:y0 + h, x0:x0 + w])
+        assert bytes(ctx32.encode_image(crop)) == bytes(octx32.encode_image(crop)), (x0, y0)
