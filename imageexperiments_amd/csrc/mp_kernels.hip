@@ -450,7 +450,9 @@ struct FilterArgs {
     const unsigned* counters_in;     // ws.counters
     unsigned* counters_out;          // same array (next step's active counts are reset here)
     const int* act[3];               // this step's active lists
-    const double* r;
+    double* r;
+    const double* upd_coeff;         // the previous step's pending residual update (0 = none): r -= coeff * atom
+    const int* upd_sel;              // ~index of a base atom, row of `detail` (this channel) otherwise
     const int* nblk;
     double* part_val;
     int* part_idx;
@@ -491,14 +493,36 @@ struct DetailFilterArgs {
 namespace {
 
 // B operand of one column group read from global memory: this lane's slot row, elements 32kk + 8h + j
-__device__ __forceinline__ double load_b_global(bf16x8 (&hi)[2], bf16x8 (&lo)[2], const double* row, int lane, bool& nonzero)
+__device__ __forceinline__ double load_b_global(bf16x8 (&hi)[2], bf16x8 (&lo)[2], double* row, const double* atom, double coeff,
+                                                int lane, bool& nonzero)
 {
-    const double2* src = (const double2*)(row + 8 * (lane >> 4));
+    double2* dst = (double2*)(row + 8 * (lane >> 4));
     double2 v[8];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-        for (int j2 = 0; j2 < 4; ++j2) v[4 * kk + j2] = src[16 * kk + j2];
+        for (int j2 = 0; j2 < 4; ++j2) v[4 * kk + j2] = dst[16 * kk + j2];
+    if (coeff != 0.0) {
+        // the residual update the finish kernel decided on (Vector::Scale then Vector::Subtract, mathvector.cpp:116-148:
+        // two roundings), applied to this lane's 16 elements on their way in and written back for the detail sweep,
+        // the exact evaluations and the next step
+        const double2* src = (const double2*)(atom + 8 * (lane >> 4));
+        double2 a[8];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int j2 = 0; j2 < 4; ++j2) a[4 * kk + j2] = src[16 * kk + j2];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const double sx = coeff * a[i].x, sy = coeff * a[i].y;
+            v[i].x = v[i].x - sx;
+            v[i].y = v[i].y - sy;
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int j2 = 0; j2 < 4; ++j2) dst[16 * kk + j2] = v[4 * kk + j2];
+    }
     double ss = 0.0;
     bool nzl = false;
 #pragma unroll
@@ -750,12 +774,16 @@ __global__ __launch_bounds__(64, MPC_WAVE_OCC) void mp_filter_wave_kernel(const 
             window[g] = 0.0f; live[g] = false; has0[g] = false;
             if (g < groups) {
                 bool nz;
-                const double ss = load_b_global(bh[g], bl[g], fa.r + (long long)tc[g] * N, lane, nz);
+                const double coeff = (with_detail0 && ok[g]) ? fa.upd_coeff[tc[g]] : 0.0;       // steps > 0 only
+                const int sel = (with_detail0 && ok[g]) ? fa.upd_sel[tc[g]] : 0;
+                const double* atom = sel < 0 ? fa.base + (long long)(~sel) * N : block0 + (long long)sel * N;
+                const double ss = load_b_global(bh[g], bl[g], fa.r + (long long)tc[g] * N, atom, coeff, lane, nz);
                 window[g] = 2.0f * (kFilterSlack * (float)__builtin_sqrt(ss) + kFilterAbs);
                 live[g] = ok[g] && nz;                          // an all-zero residual projects to 0 everywhere: index -1
                 has0[g] = with_detail0 && ok[g] && nblk_has0(fa.nblk[tc[g]]);
             }
         }
+        __threadfence_block();                                  // the updated residuals are read back lane = pixel below
         auto tile_ptr = [&](int tile) {
             return (const uint4*)(tile < kBaseFilterTiles ? fa.base_f32 + tile * 2048 : tiles0 + (tile - kBaseFilterTiles) * 2048) + lane;
         };
@@ -1507,6 +1535,8 @@ FilterArgs filter_args(const Workspace& ws, const DictDevice& dict, int cur)
         fa.block0_f32[ch] = dict.detail_f32 + (long long)ch * dict.num_base * kBlockFilterTiles * 2048;
     }
     fa.r = ws.r;
+    fa.upd_coeff = ws.upd_coeff;
+    fa.upd_sel = ws.upd_sel;
     fa.nblk = ws.nblk;
     fa.part_val = ws.part_val;
     fa.part_idx = ws.part_idx;
@@ -1569,7 +1599,7 @@ int enqueue_pursuit(const DictDevice& dict, const Workspace& ws, const FrameInpu
         if (step > 0) {
             hipLaunchKernelGGL(mp_bucket_kernel, dim3(1), dim3(1024), 0, s, ws, step & 1);
             hipLaunchKernelGGL(mp_fill_kernel, dim3(clampu(max_slabs, 2048u)), dim3(256), 0, s, ws, cur);
-            if (forked) (void)hipStreamWaitEvent(s, ev_join, 0);          // the previous step's residual update
+            if (forked && !filtered) (void)hipStreamWaitEvent(s, ev_join, 0);   // the previous step's residual update
         }
         if (base_events) (void)hipEventRecord(static_cast<hipEvent_t>(base_events[2 * step]), s);
         if (filtered)
@@ -1595,12 +1625,12 @@ int enqueue_pursuit(const DictDevice& dict, const Workspace& ws, const FrameInpu
         if (step + 1 < K) {
             // The residual update and the next step's bucket + fill only depend on the finish kernel, not on each other:
             // with a side stream the update runs beside them and is joined in front of the next sweep.
-            if (forked) {
+            if (forked && !filtered) {
                 (void)hipEventRecord(ev_fork, s);
                 (void)hipStreamWaitEvent(side, ev_fork, 0);
                 hipLaunchKernelGGL(mp_update_kernel, dim3(clampu(max_groups, 4096u)), dim3(64), 0, side, ws, dict, cur);
                 (void)hipEventRecord(ev_join, side);
-            } else {
+            } else if (!filtered) {                               // the filter kernel applies the update as it reads the residuals
                 hipLaunchKernelGGL(mp_update_kernel, dim3(clampu(max_groups, 4096u)), dim3(64), 0, s, ws, dict, cur);
             }
         }
