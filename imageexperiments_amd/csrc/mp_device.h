@@ -6,8 +6,8 @@
 //
 //   init      gather tile + YUVFromRGB -> residual r[tc][64], reset state        (CompressedImage.cpp:538-554)
 //   per step s = 0..K-1:
-//     bucket   (s>0) prefix-sum the per-block item counts, emit chunk descriptors
-//     fill     (s>0) scatter (tile-channel, block) items into their block's bucket
+//     fill     (s>0) prefix-sum the per-block item counts (every workgroup for itself; workgroup 0 emits the chunk
+//              descriptors), scatter (tile-channel, block) items into their block's bucket
 //     filter   the 510 shared base atoms and (s>0) DetailBasis[0], the block the DC atom unlocks for nearly every
 //              tile (no bucketing): best exact projection of each                  (Select, MatchingPursuit.cpp:7-25)
 //     detail   (s>0) every other unlocked detail block, bucketed by (channel, block)

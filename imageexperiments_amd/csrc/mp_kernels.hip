@@ -74,6 +74,7 @@ __global__ __launch_bounds__(64) void mp_init_kernel(const Workspace ws, const F
         for (int b = lane; b < kNumBuckets; b += 64) {
             ws.bucket_count[0][b] = 0;
             ws.bucket_count[1][b] = 0;
+            ws.bucket_cursor[b] = 0;
         }
         if (lane < 3) {
             ws.counters[lane] = vec ? (lane == in.vec_channel ? (unsigned)n : 0u) : (unsigned)(n / 3);
@@ -1038,64 +1039,78 @@ __global__ __launch_bounds__(64) void mp_detail_filter_kernel(const DetailFilter
 }
 
 // --------------------------------------------------------------------------------------------------
-// bucket: exclusive scan of the per-(channel, block) item counts, chunk descriptors, counter resets.
-// One workgroup of 1024 threads; 1536 buckets.
-// --------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void mp_bucket_kernel(const Workspace ws, int cur_cnt)
-{
-    __shared__ unsigned s_items[2048];
-    __shared__ unsigned s_chunks[2048];
-    const int t = threadIdx.x;
-    const unsigned* cnt = ws.bucket_count[cur_cnt];
-    unsigned* nxt = ws.bucket_count[cur_cnt ^ 1];
-    for (int b = t; b < 2048; b += 1024) {
-        const unsigned c = (b < kNumBuckets) ? cnt[b] : 0u;
-        s_items[b] = c;
-        s_chunks[b] = (c + kChunkItems - 1) / kChunkItems;
-    }
-    __syncthreads();
-    // Hillis-Steele inclusive scan over 2048 entries, two per thread
-    for (int d = 1; d < 2048; d <<= 1) {
-        unsigned a0 = 0, a1 = 0, c0 = 0, c1 = 0;
-        const int i0 = t, i1 = t + 1024;
-        if (i0 >= d) { a0 = s_items[i0 - d]; c0 = s_chunks[i0 - d]; }
-        if (i1 >= d) { a1 = s_items[i1 - d]; c1 = s_chunks[i1 - d]; }
-        __syncthreads();
-        s_items[i0] += a0; s_chunks[i0] += c0;
-        s_items[i1] += a1; s_chunks[i1] += c1;
-        __syncthreads();
-    }
-    for (int b = t; b < kNumBuckets; b += 1024) {
-        const unsigned c = cnt[b];
-        const unsigned start = s_items[b] - c;                 // exclusive
-        const unsigned nch = (c + kChunkItems - 1) / kChunkItems;
-        const unsigned coff = s_chunks[b] - nch;
-        ws.bucket_start[b] = start;
-        ws.bucket_cursor[b] = 0;
-        nxt[b] = 0;
-        for (unsigned k = 0; k < nch; ++k) {
-            const unsigned lo = start + k * kChunkItems;
-            const unsigned hi = (lo + kChunkItems < start + c) ? lo + kChunkItems : start + c;
-            int* d = ws.chunks + 4 * (long long)(coff + k);
-            d[0] = b; d[1] = (int)lo; d[2] = (int)hi; d[3] = 0;
-        }
-    }
-    if (t == 0) {
-        ws.bucket_start[kNumBuckets] = s_items[kNumBuckets - 1];
-        ws.counters[6] = 0;                                     // chunk cursor
-        ws.counters[7] = s_chunks[kNumBuckets - 1];             // chunks this step
-        ws.counters[8] = s_items[kNumBuckets - 1];              // items this step
-    }
-}
-
 // fill: each active tile-channel drops one item per unlocked, non-repeated block (block 0 excepted) into
 // that block's bucket and remembers the slot.  A slab of 256 list entries (one channel) first ranks its items
 // per block in LDS, reserves one range per touched bucket with a single global atomic, then scatters: popular
 // blocks would otherwise serialise tens of thousands of same-address atomics per step.
-__global__ __launch_bounds__(256) void mp_fill_kernel(const Workspace ws, int cur)
+__global__ __launch_bounds__(256) void mp_fill_kernel(const Workspace ws, int cur, int cur_cnt)
 {
     __shared__ unsigned s_cnt[512];
     __shared__ unsigned s_base[512];
+    // Every workgroup first turns the per-(channel, block) item counts the finish kernel left into bucket ranges by an
+    // exclusive scan of its own (1536 counts, six per thread: cheaper than a launch for one workgroup to do it once);
+    // workgroup 0 also writes the chunk descriptors and counters the detail sweep reads, and clears the other count
+    // buffer for the finish kernel that follows.
+    __shared__ unsigned s_scan_items[256];
+    __shared__ unsigned s_scan_chunks[256];
+    __shared__ unsigned s_start[kNumBuckets];
+    __shared__ unsigned s_coff[kNumBuckets + 1];
+    {
+        constexpr int kPer = kNumBuckets / 256;               // 6
+        static_assert(kPer * 256 == kNumBuckets, "six buckets per thread");
+        const int t = threadIdx.x;
+        const unsigned* cnt = ws.bucket_count[cur_cnt];
+        unsigned c[kPer];
+        unsigned items = 0, chunks = 0;
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            c[k] = cnt[t * kPer + k];
+            items += c[k];
+            chunks += (c[k] + kChunkItems - 1) / kChunkItems;
+        }
+        s_scan_items[t] = items;
+        s_scan_chunks[t] = chunks;
+        __syncthreads();
+        for (int d = 1; d < 256; d <<= 1) {                    // Hillis-Steele inclusive scan
+            unsigned a = 0, b = 0;
+            if (t >= d) { a = s_scan_items[t - d]; b = s_scan_chunks[t - d]; }
+            __syncthreads();
+            s_scan_items[t] += a;
+            s_scan_chunks[t] += b;
+            __syncthreads();
+        }
+        unsigned start = s_scan_items[t] - items, coff = s_scan_chunks[t] - chunks;
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            s_start[t * kPer + k] = start;
+            s_coff[t * kPer + k] = coff;
+            start += c[k];
+            coff += (c[k] + kChunkItems - 1) / kChunkItems;
+        }
+        const unsigned total_chunks = s_scan_chunks[255], total_items = s_scan_items[255];
+        if (t == 255) s_coff[kNumBuckets] = total_chunks;
+        __syncthreads();
+        if (blockIdx.x == 0) {
+            unsigned* nxt = ws.bucket_count[cur_cnt ^ 1];
+            for (int b = t; b < kNumBuckets; b += 256) nxt[b] = 0;
+            if (t == 0) {
+                ws.counters[6] = 0;                             // chunk cursor
+                ws.counters[7] = total_chunks;                  // chunks this step
+                ws.counters[8] = total_items;                   // items this step
+            }
+            for (unsigned j = (unsigned)t; j < total_chunks; j += 256) {
+                int lo = 0, hi = kNumBuckets;                   // the bucket b with s_coff[b] <= j < s_coff[b + 1]
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (s_coff[mid] <= j) lo = mid; else hi = mid;
+                }
+                const unsigned first = s_start[lo] + (j - s_coff[lo]) * kChunkItems;
+                const unsigned end = (lo + 1 < kNumBuckets) ? s_start[lo + 1] : total_items;
+                int* d = ws.chunks + 4 * (long long)j;
+                d[0] = lo; d[1] = (int)first; d[2] = (int)(first + kChunkItems < end ? first + kChunkItems : end); d[3] = 0;
+            }
+        }
+    }
     const int s0 = ((int)ws.counters[cur * 3 + 0] + 255) >> 8, s1 = ((int)ws.counters[cur * 3 + 1] + 255) >> 8,
               s2 = ((int)ws.counters[cur * 3 + 2] + 255) >> 8;
     for (int b = threadIdx.x; b < 512; b += 256) s_cnt[b] = 0;
@@ -1120,7 +1135,7 @@ __global__ __launch_bounds__(256) void mp_fill_kernel(const Workspace ws, int cu
             const unsigned c = s_cnt[b];
             if (c) {
                 const int gb = (ch << 9) | b;
-                s_base[b] = ws.bucket_start[gb] + atomicAdd(&ws.bucket_cursor[gb], c);
+                s_base[b] = s_start[gb] + atomicAdd(&ws.bucket_cursor[gb], c);
                 s_cnt[b] = 0;
             }
         }
@@ -1154,6 +1169,8 @@ __global__ __launch_bounds__(256) void mp_finish_kernel(const Workspace ws, cons
               s2 = ((int)ws.counters[cur * 3 + 2] + 255) >> 8;
     __shared__ unsigned s_cnt[512];          // next step's items per block, counted per slab before going global
     for (int b = threadIdx.x; b < 512; b += 256) s_cnt[b] = 0;
+    if (blockIdx.x == 0)                     // the fill kernel of this step is done with its bucket cursors: clear for the next
+        for (int b = threadIdx.x; b < kNumBuckets; b += 256) ws.bucket_cursor[b] = 0;
     __syncthreads();
     for (int slab = blockIdx.x; slab < s0 + s1 + s2; slab += gridDim.x) {
     const int ch = slab < s0 ? 0 : (slab < s0 + s1 ? 1 : 2);
@@ -1597,8 +1614,7 @@ int enqueue_pursuit(const DictDevice& dict, const Workspace& ws, const FrameInpu
     for (int step = 0; step < K; ++step) {
         const int cur = step & 1;
         if (step > 0) {
-            hipLaunchKernelGGL(mp_bucket_kernel, dim3(1), dim3(1024), 0, s, ws, step & 1);
-            hipLaunchKernelGGL(mp_fill_kernel, dim3(clampu(max_slabs, 2048u)), dim3(256), 0, s, ws, cur);
+            hipLaunchKernelGGL(mp_fill_kernel, dim3(clampu(max_slabs, 2048u)), dim3(256), 0, s, ws, cur, step & 1);
             if (forked && !filtered) (void)hipStreamWaitEvent(s, ev_join, 0);   // the previous step's residual update
         }
         if (base_events) (void)hipEventRecord(static_cast<hipEvent_t>(base_events[2 * step]), s);
