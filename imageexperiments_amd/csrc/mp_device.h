@@ -67,7 +67,6 @@ struct Workspace {
     int* act[2][3];                  // [cap] active tile-channels per channel (ping-pong)
     unsigned* counters;              // [16]: [cur*3+ch] = active count; 6 = chunk cursor; 7 = n_chunks; 8 = n_items
     unsigned* bucket_count[2];       // [kNumBuckets] items per (channel, block) for this / the next step
-    unsigned* bucket_start;          // [kNumBuckets + 1]
     unsigned* bucket_cursor;         // [kNumBuckets]
     int* chunks;                     // [max_chunks][4] = bucket, begin, end, 0
     int* items;                      // [max_items] tile-channel of each item

@@ -1520,7 +1520,6 @@ Workspace carve(char* mem, int cap, int K, size_t* total)
     w.counters = c.take<unsigned>(16);
     w.bucket_count[0] = c.take<unsigned>(kNumBuckets);
     w.bucket_count[1] = c.take<unsigned>(kNumBuckets);
-    w.bucket_start = c.take<unsigned>(kNumBuckets + 1);
     w.bucket_cursor = c.take<unsigned>(kNumBuckets);
     w.chunks = c.take<int>(static_cast<size_t>(w.max_chunks) * 4);
     w.items = c.take<int>(static_cast<size_t>(w.max_items));
