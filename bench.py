@@ -181,10 +181,11 @@ def main():
     active = np.array([int(cnt_hist[s:].sum()) for s in range(K)], dtype=np.int64)
     sweeps = int(active.sum())                                          # = sum over tile-channels of min(count+1, K)
     # The dominant kernel (mp_filter_wave_kernel) runs the base rows (512 with the zero pads; + 64 of DetailBasis[0] from
-    # step 1 on) of every active tile-channel through the matrix cores TWICE (maximum, then threshold), each product as
-    # three bf16 MFMAs (hi*hi + hi*lo + lo*hi): executed MFMA flops per launch = 2 passes x 3 x 2*64*rows x tile-channels.
+    # step 1 on) of every active tile-channel through the matrix cores, each product as three bf16 MFMAs (hi*hi + hi*lo +
+    # lo*hi): executed MFMA flops per launch >= 3 x 2*64*rows x tile-channels (a second pass only for the column groups
+    # where a runner-up reaches the threshold, ~1 % of the tile-channels: not counted).
     rows_per_step = np.array([512 + (64 if s > 0 else 0) for s in range(K)], dtype=np.int64)
-    mfma_flops_per_step = float((active * rows_per_step).sum()) * 2 * 3 * 2 * 64
+    mfma_flops_per_step = float((active * rows_per_step).sum()) * 3 * 2 * 64
     # what the reference's algorithm asks of the same rows: one 64-term dot product per (tile-channel, row)
     algorithmic_flops_per_step = float((active * np.array([510 + (63 if s > 0 else 0) for s in range(K)])).sum()) * 2 * 64
     base_ms = base_ms_total / max(base_launches, 1)                     # average duration of ONE launch of it
@@ -246,7 +247,8 @@ def main():
                                  "510 base rows + 63 of block 0 from step 1 on, per active tile-channel) over the union of the kernel's "
                                  "launch intervals; > HBM peak because no dictionary row is fetched from HBM and few are touched in "
                                  "double.  traffic = PMC FETCH/WRITE bytes of a whole bench step (profiles/r01_pmc_*.json).  mfma = "
-                                 "executed matrix-core flops (2 passes x 3 split-bf16 products) against the dense bf16 peak; the "
+                                 "executed matrix-core flops (3 split-bf16 products per element, the rare second pass not counted) against the dense "
+                                 "bf16 peak; the "
                                  "kernel is bound by memory latency and the serial exact evaluations (DESIGN.md 3, 9)"},
         }
         if not args.no_cpu and world == 1:
