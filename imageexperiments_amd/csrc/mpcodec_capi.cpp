@@ -68,6 +68,9 @@ struct mpc_context {
     size_t stage_bytes = 0;
     void* host_stage = nullptr;       // pinned: records of mpc_encode_image on their way to the entropy stage
     size_t host_stage_bytes = 0;
+    // mpc_encode_images: upload / compute / download streams and per-slot events (upload done, pursuit done, download done)
+    hipStream_t seq_up = nullptr, seq_compute = nullptr, seq_down = nullptr;
+    hipEvent_t seq_events[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
     // The pursuit of a call is cut into sub-batches that run on `pipes` internal streams, each with its own
     // workspace: the latency-bound bookkeeping kernels of one sub-batch (finish, update, bucket, fill) overlap
     // the machine-filling sweeps of the other.  Fork/join with events on the caller's stream: still no host
@@ -304,6 +307,12 @@ void mpc_context_destroy(mpc_context* c) {
         (void)hipFree(c->d_flag);
         (void)hipFree(c->stage);
         if (c->host_stage) (void)hipHostFree(c->host_stage);
+        if (c->seq_up) (void)hipStreamDestroy(c->seq_up);
+        if (c->seq_compute) (void)hipStreamDestroy(c->seq_compute);
+        if (c->seq_down) (void)hipStreamDestroy(c->seq_down);
+        for (auto& slot : c->seq_events)
+            for (hipEvent_t e : slot)
+                if (e) (void)hipEventDestroy(e);
         for (auto& p : c->pipes) {
             if (p.mem) (void)hipFree(p.mem);
             if (p.stream) (void)hipStreamDestroy(p.stream);
@@ -743,6 +752,7 @@ mpc_status mpc_encode_images(mpc_context* c, const uint8_t* const* rgb_frames, i
                              const double* quant, uint8_t** bytes, size_t* nbytes) {
     if (!c || !rgb_frames || !bytes || !nbytes || n_frames < 1) return fail(MPC_ERR_ARGUMENT, "bad argument");
     if (c->device < 0) return fail(MPC_ERR_NO_DEVICE, "context was created without a device; there is no CPU fallback");
+    if (width < 1 || height < 1) return fail(MPC_ERR_ARGUMENT, "bad geometry");
     for (int f = 0; f < n_frames; ++f) {
         if (!rgb_frames[f]) return fail(MPC_ERR_ARGUMENT, "null frame");
         bytes[f] = nullptr;
@@ -750,18 +760,39 @@ mpc_status mpc_encode_images(mpc_context* c, const uint8_t* const* rgb_frames, i
     }
     const int tiles_y = (height + 7) / 8;
     const size_t tiles = static_cast<size_t>((width + 7) / 8) * tiles_y;
+    const size_t n_tc = tiles * 3;
     HIP_TRY(hipSetDevice(c->device));
-    // two pinned record buffers: the entropy stage reads one while the device fills the other
-    const size_t counts_bytes = (sizeof(uint16_t) * tiles * 3 + 255) & ~static_cast<size_t>(255);
-    const size_t slot_bytes = counts_bytes + ((sizeof(mpc_basis_choice) * tiles * 3 * c->K + 255) & ~static_cast<size_t>(255));
-    if (2 * slot_bytes > c->host_stage_bytes) {
+    // Three stages, two slots: while the device encodes frame f (compute stream), frame f+1 is uploaded (upload stream;
+    // pageable memory, so the call blocks this thread, not the device), the records of frame f-1 travel to pinned host
+    // memory (download stream) and a worker codes them into their container.
+    auto up = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
+    const size_t img_bytes = static_cast<size_t>(3) * width * height;
+    const size_t counts_bytes = up(sizeof(uint16_t) * n_tc), choices_bytes = up(sizeof(mpc_basis_choice) * n_tc * c->K);
+    const size_t host_slot = counts_bytes + choices_bytes, dev_slot = up(img_bytes) + host_slot;
+    if (2 * host_slot > c->host_stage_bytes) {
         if (c->host_stage) (void)hipHostFree(c->host_stage);
         c->host_stage = nullptr;
         c->host_stage_bytes = 0;
-        const hipError_t e = hipHostMalloc(&c->host_stage, 2 * slot_bytes, hipHostMallocDefault);
-        if (e != hipSuccess) return fail(MPC_ERR_ALLOC, "pinned staging of %zu bytes: %s", 2 * slot_bytes, hipGetErrorString(e));
-        c->host_stage_bytes = 2 * slot_bytes;
+        const hipError_t e = hipHostMalloc(&c->host_stage, 2 * host_slot, hipHostMallocDefault);
+        if (e != hipSuccess) return fail(MPC_ERR_ALLOC, "pinned staging of %zu bytes: %s", 2 * host_slot, hipGetErrorString(e));
+        c->host_stage_bytes = 2 * host_slot;
     }
+    if (2 * dev_slot > c->stage_bytes) {
+        if (c->stage) (void)hipFree(c->stage);
+        c->stage = nullptr;
+        c->stage_bytes = 0;
+        const hipError_t e = hipMalloc(&c->stage, 2 * dev_slot);
+        if (e != hipSuccess) return fail(MPC_ERR_ALLOC, "device staging of %zu bytes: %s", 2 * dev_slot, hipGetErrorString(e));
+        c->stage_bytes = 2 * dev_slot;
+    }
+    if (!c->seq_up) {
+        HIP_TRY(hipStreamCreateWithFlags(&c->seq_up, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&c->seq_compute, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&c->seq_down, hipStreamNonBlocking));
+        for (auto& slot : c->seq_events)
+            for (hipEvent_t& e : slot) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    HIP_TRY(ensure_workspace(c, static_cast<long long>(n_tc)) == MPC_OK ? hipSuccess : hipErrorOutOfMemory);
     const double* q = quant ? quant : c->quant.data();
     struct Pending {
         std::future<std::vector<uint8_t>> result;
@@ -772,29 +803,63 @@ mpc_status mpc_encode_images(mpc_context* c, const uint8_t* const* rgb_frames, i
         if (p.frame < 0) return;
         std::vector<uint8_t> blob = p.result.get();
         if (st == MPC_OK) {
-            bytes[p.frame] = give_bytes(blob, &nbytes[p.frame]);
-            if (!bytes[p.frame]) st = fail(MPC_ERR_ALLOC, "out of memory");
+            if (blob.empty()) st = fail(MPC_ERR_HIP, "record download failed");
+            else {
+                bytes[p.frame] = give_bytes(blob, &nbytes[p.frame]);
+                if (!bytes[p.frame]) st = fail(MPC_ERR_ALLOC, "out of memory");
+            }
         }
         p.frame = -1;
     };
+#define MPC_SEQ_TRY(call)                                                                         \
+    {                                                                                             \
+        const hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess) { st = fail(MPC_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); break; } \
+    }
+    bool used[2] = {false, false};                                // the slot's events have been recorded at least once
     for (int f = 0; f < n_frames && st == MPC_OK; ++f) {
-        Pending& slot = pending[f & 1];
-        collect(slot);                                            // frame f-2 is done with this buffer
+        const int sl = f & 1;
+        Pending& slot = pending[sl];
+        collect(slot);                                            // frame f-2 has left this slot's pinned buffer
         if (st != MPC_OK) break;
-        char* base = static_cast<char*>(c->host_stage) + static_cast<size_t>(f & 1) * slot_bytes;
-        uint16_t* counts = reinterpret_cast<uint16_t*>(base);
-        mpc_basis_choice* choices = reinterpret_cast<mpc_basis_choice*>(base + counts_bytes);
-        st = mpc_encode_tiles(c, rgb_frames[f], width, height, static_cast<size_t>(3) * width, 0, tiles_y, quant, counts, choices,
-                              nullptr, nullptr);
+        char* dbase = static_cast<char*>(c->stage) + static_cast<size_t>(sl) * dev_slot;
+        uint8_t* d_rgb = reinterpret_cast<uint8_t*>(dbase);
+        uint16_t* d_counts = reinterpret_cast<uint16_t*>(dbase + up(img_bytes));
+        mpc_basis_choice* d_choices = reinterpret_cast<mpc_basis_choice*>(dbase + up(img_bytes) + counts_bytes);
+        char* hbase = static_cast<char*>(c->host_stage) + static_cast<size_t>(sl) * host_slot;
+        uint16_t* counts = reinterpret_cast<uint16_t*>(hbase);
+        mpc_basis_choice* choices = reinterpret_cast<mpc_basis_choice*>(hbase + counts_bytes);
+        hipEvent_t ev_up = c->seq_events[sl][0], ev_comp = c->seq_events[sl][1], ev_down = c->seq_events[sl][2];
+        // upload: the pursuit of frame f-2 must be done with this slot's image
+        if (used[sl]) MPC_SEQ_TRY(hipStreamWaitEvent(c->seq_up, ev_comp, 0));
+        MPC_SEQ_TRY(hipMemcpyAsync(d_rgb, rgb_frames[f], img_bytes, hipMemcpyHostToDevice, c->seq_up));
+        MPC_SEQ_TRY(hipEventRecord(ev_up, c->seq_up));
+        // compute: after the upload, and after frame f-2's records have left the device buffers
+        MPC_SEQ_TRY(hipStreamWaitEvent(c->seq_compute, ev_up, 0));
+        if (used[sl]) MPC_SEQ_TRY(hipStreamWaitEvent(c->seq_compute, ev_down, 0));
+        st = mpc_encode_tiles_device(c, d_rgb, width, height, static_cast<size_t>(3) * width, 0, tiles_y, quant, d_counts, d_choices,
+                                     nullptr, nullptr, 0, c->seq_compute);
         if (st != MPC_OK) break;
-        const int K = c->K, bs = c->block_size;
+        MPC_SEQ_TRY(hipEventRecord(ev_comp, c->seq_compute));
+        // download into the pinned slot
+        MPC_SEQ_TRY(hipStreamWaitEvent(c->seq_down, ev_comp, 0));
+        MPC_SEQ_TRY(hipMemcpyAsync(counts, d_counts, sizeof(uint16_t) * n_tc, hipMemcpyDeviceToHost, c->seq_down));
+        MPC_SEQ_TRY(hipMemcpyAsync(choices, d_choices, sizeof(mpc_basis_choice) * n_tc * c->K, hipMemcpyDeviceToHost, c->seq_down));
+        MPC_SEQ_TRY(hipEventRecord(ev_down, c->seq_down));
+        used[sl] = true;
+        const int K = c->K, bs = c->block_size, device = c->device;
         slot.frame = f;
-        slot.result = std::async(std::launch::async, [=] {
+        slot.result = std::async(std::launch::async, [=]() -> std::vector<uint8_t> {
+            if (hipSetDevice(device) != hipSuccess || hipEventSynchronize(ev_down) != hipSuccess) return {};
             return mpc::encode_records(width, height, K, bs, q, counts, reinterpret_cast<const uint32_t*>(choices));
         });
     }
+#undef MPC_SEQ_TRY
     collect(pending[0]);
     collect(pending[1]);
+    (void)hipStreamSynchronize(c->seq_up);
+    (void)hipStreamSynchronize(c->seq_compute);
+    (void)hipStreamSynchronize(c->seq_down);
     if (st != MPC_OK) {
         for (int f = 0; f < n_frames; ++f) { std::free(bytes[f]); bytes[f] = nullptr; nbytes[f] = 0; }
     }
