@@ -317,29 +317,42 @@ struct Entry {
 
 }  // namespace
 
-// Huffman.cpp:46-163
-void huffman_encode(const uint16_t* data, size_t n, BitWriter& out) {
-    // lookup tables only as large as the largest symbol (streams of small numbers: no 64K-entry tables to clear per stream)
+namespace {
+// One pass over a stream: histogram (only as large as the largest symbol: no 64K-entry tables to clear per stream) and
+// the distinct symbols in order of first appearance -- the order the reference inserts them into its unordered_map.
+struct SymbolStats {
     uint16_t largest = 0;
-    for (size_t i = 0; i < n; ++i) largest = std::max(largest, data[i]);
-    const size_t table_size = static_cast<size_t>(largest) + 1;
-    std::vector<int> leaf_of(table_size, -1);
-    std::vector<uint32_t> symbols;
+    std::vector<uint32_t> hist;
+    std::vector<uint16_t> distinct;
+};
+
+SymbolStats gather_stats(const uint16_t* data, size_t n) {
+    SymbolStats st;
+    for (size_t i = 0; i < n; ++i) st.largest = std::max(st.largest, data[i]);
+    st.hist.assign(static_cast<size_t>(st.largest) + 1, 0);
+    for (size_t i = 0; i < n; ++i)
+        if (st.hist[data[i]]++ == 0) st.distinct.push_back(data[i]);
+    return st;
+}
+
+void huffman_encode_with(const SymbolStats& st, const uint16_t* data, size_t n, BitWriter& out);
+}  // namespace
+
+// Huffman.cpp:46-163
+void huffman_encode(const uint16_t* data, size_t n, BitWriter& out) { huffman_encode_with(gather_stats(data, n), data, n, out); }
+
+namespace {
+void huffman_encode_with(const SymbolStats& st, const uint16_t* data, size_t n, BitWriter& out) {
+    const size_t table_size = static_cast<size_t>(st.largest) + 1;
+    std::vector<uint32_t> symbols(st.distinct.begin(), st.distinct.end());
     std::vector<size_t> freq;
+    freq.reserve(symbols.size() + 1);
     MsvcHashOrder order;
-    uint8_t symbol_bits = 1;
-    for (size_t i = 0; i < n; ++i) {
-        const uint32_t s = data[i];
-        symbol_bits = std::max<uint8_t>(symbol_bits, static_cast<uint8_t>(bit_width(s)));
-        int& leaf = leaf_of[s];
-        if (leaf < 0) {
-            leaf = static_cast<int>(symbols.size());
-            symbols.push_back(s);
-            freq.push_back(0);
-            order.insert(s);                                   // node id == leaf + 1
-        }
-        ++freq[leaf];
+    for (uint32_t s : symbols) {
+        freq.push_back(st.hist[s]);
+        order.insert(s);                                       // node id == leaf + 1
     }
+    const uint8_t symbol_bits = std::max<uint8_t>(1, static_cast<uint8_t>(bit_width(st.largest)));
     const int eof_leaf = static_cast<int>(symbols.size());
     symbols.push_back(kPseudoEof);
     freq.push_back(0);
@@ -424,6 +437,7 @@ void huffman_encode(const uint16_t* data, size_t n, BitWriter& out) {
     out.put_codes(data, n, code_of.data(), length_of.data(), payload_bits);
     out.put(eof_code, eof_length);
 }
+}  // namespace
 
 // Huffman.cpp:173-244
 bool huffman_decode(BitReader& in, std::vector<uint16_t>& out) {
@@ -564,19 +578,14 @@ std::vector<uint16_t> rle_decode(const uint16_t* data, size_t n) {
 // CompressedImage.cpp:359-401.  The Golomb cost of each candidate M is the sum over DISTINCT symbols of
 // count x length -- same number as the reference's per-symbol loop.
 void write_huffman_or_golomb(const uint16_t* data, size_t n, BitWriter& out) {
+    const SymbolStats st = gather_stats(data, n);
     BitWriter huff;
-    huffman_encode(data, n, huff);
+    huffman_encode_with(st, data, n, huff);
     size_t best = huff.bit_size();
     int best_m = -1;
-    uint16_t largest = 0;
-    for (size_t i = 0; i < n; ++i) largest = std::max(largest, data[i]);
-    std::vector<uint32_t> hist(static_cast<size_t>(largest) + 1, 0);
-    std::vector<uint16_t> distinct;
-    for (size_t i = 0; i < n; ++i)
-        if (hist[data[i]]++ == 0) distinct.push_back(data[i]);
     for (int m = 1; m < 2048; m = (m & 1) ? m + 1 : (m << 1) - 1) {
         size_t estimate = 16;
-        for (uint16_t s : distinct) estimate += static_cast<size_t>(hist[s]) * golomb_length(s, static_cast<uint32_t>(m));
+        for (uint16_t s : st.distinct) estimate += static_cast<size_t>(st.hist[s]) * golomb_length(s, static_cast<uint32_t>(m));
         if (estimate < best) { best = estimate; best_m = m; }
     }
     if (best_m < 0) {
@@ -779,11 +788,12 @@ std::vector<uint8_t> encode_records(int width, int height, int K, int block_size
         }
     };
     // the big jobs first: step 0 of every channel holds every tile-channel, later steps fewer
-    parallel_for(3 * K + 1, [&](int job) {
-        if (job == 3 * K) {
-            write_huffman_or_golomb(counts, 3 * tiles, parts[0]);                              // the lengths stream
+    parallel_for(3 * K + 1, [&](int job0) {
+        if (job0 == 0) {
+            write_huffman_or_golomb(counts, 3 * tiles, parts[0]);                              // the lengths stream: the longest
             return;
         }
+        const int job = job0 - 1;
         const int i = job / 3, ch = job - 3 * i;                 // job order: (step 0: Y U V), (step 1: Y U V), ...
         thread_local std::vector<uint16_t> d, c, scratch;
         d.clear();
