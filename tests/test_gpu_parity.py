@@ -419,3 +419,16 @@ def test_natural_image_crops_bytes_equal_oracle(gpu, oracle, ctx32, octx32, mn_b
     for (x0, y0, w, h) in ((1000, 800, 256, 192), (3000, 2000, 320, 160), (0, 0, 200, 120), (4600, 3100, 328, 164)):
         crop = np.ascontiguousarray(photo[y0:y0 + h, x0:x0 + w])
         assert bytes(ctx32.encode_image(crop)) == bytes(octx32.encode_image(crop)), (x0, y0)
+
+
+@pytest.mark.parametrize("env", [{"MPC_NO_SMALL": "1"}, {"MPC_PIPES": "1"}, {"MPC_PIPES": "4"}, {"MPC_FILTER": "0"}])
+def test_launch_configurations_do_not_change_records(gpu, oracle, monkeypatch, env):
+    """the large-batch kernel instantiation on a small frame, other sub-batch counts, the exhaustive sweep: same records"""
+    import imageexperiments_amd as ia
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rgb = oracle.synth_frame(328, 208, 321)
+    ctx = ia.create_compression_context(16, 8, 3.0, device=0)
+    octx = oracle.OracleContext(16, 8, 3.0)
+    _compare(ctx.encode_tiles(rgb), octx.encode_tiles(rgb), 16)
+    ctx.close()
