@@ -133,6 +133,31 @@ inline std::unique_ptr<uint8_t[]> encodeImage(const img::image<img::rgb>* imgIn,
     return out;
 }
 
+// encodeImage for a sequence of equally sized frames (Compression.cpp:117/166 calls encodeImage once per input file):
+// the host entropy stage of frame n overlaps the transfers and the device encode of frame n+1 (mpc_encode_images)
+inline std::vector<std::vector<uint8_t>> encodeImages(const std::vector<const img::image<img::rgb>*>& frames,
+                                                      const CompressionContext& context, const double quantY[],
+                                                      const double quantU[], const double quantV[]) {
+    const size_t K = context.K;
+    std::vector<double> q(3 * K);
+    std::memcpy(q.data(), quantY, K * sizeof(double));
+    std::memcpy(q.data() + K, quantU, K * sizeof(double));
+    std::memcpy(q.data() + 2 * K, quantV, K * sizeof(double));
+    std::vector<std::vector<uint8_t>> out;
+    if (frames.empty()) return out;
+    std::vector<const uint8_t*> ptrs;
+    for (const img::image<img::rgb>* f : frames) ptrs.push_back(reinterpret_cast<const uint8_t*>(f->data));
+    std::vector<uint8_t*> bytes(frames.size(), nullptr);
+    std::vector<size_t> sizes(frames.size(), 0);
+    detail::check(mpc_encode_images(context.handle, ptrs.data(), static_cast<int>(frames.size()), static_cast<int>(frames[0]->width()),
+                                    static_cast<int>(frames[0]->height()), q.data(), bytes.data(), sizes.data()));
+    for (size_t i = 0; i < frames.size(); ++i) {
+        out.emplace_back(bytes[i], bytes[i] + sizes[i]);
+        mpc_free(bytes[i]);
+    }
+    return out;
+}
+
 inline std::unique_ptr<img::image<img::rgb>> decodeImage(const uint8_t bytes[], size_t byteSize,
                                                          const CompressionContext* context = nullptr) {
     uint8_t* rgb = nullptr;
