@@ -176,3 +176,18 @@ def test_invalid_container_is_an_error(ia, mn_bytes):
     assert e.value.status == ia.api.MPC_ERR_BITSTREAM
     with pytest.raises(ia.MpcError):
         ia.read_compressed(mn_bytes[:1000])
+
+
+@pytest.mark.parametrize("size,K,bpp,threads", [((96, 64), 8, 3.5, "1"), ((72, 40), 32, 3.5, "3"), ((130, 50), 16, 2.0, "16"),
+                                                ((8, 8), 4, 6.0, "2")])
+def test_records_to_container_equals_oracle(ia, oracle, monkeypatch, size, K, bpp, threads):
+    """mpc_assemble_streams (records -> container in one pass per (channel, step), worker pool): bytes equal the oracle's
+    encodeImage on the same records, whatever the number of host threads"""
+    monkeypatch.setenv("MPC_HOST_THREADS", threads)
+    w, h = size
+    rgb = oracle.synth_frame(w, h, 7 + K)
+    octx = oracle.OracleContext(K, 8, bpp)
+    counts, delta, coef, _, _ = octx.encode_tiles(rgb)
+    choices = delta.astype(np.uint32) | (coef.astype(np.uint32) << 16)
+    blob = ia.assemble_streams(w, h, K, 8, octx.quant, counts, choices)
+    assert bytes(blob) == bytes(octx.encode_image(rgb))
