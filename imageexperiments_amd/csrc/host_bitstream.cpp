@@ -758,11 +758,11 @@ std::vector<uint8_t> write_compressed(const Streams& s) {
 // assemble_streams + write_compressed in one go, without materialising the 6K streams of a frame (hundreds of MB of
 // freshly faulted pages at K = 32): one job per (channel, step) gathers its two streams into buffers the worker thread
 // keeps between calls and codes them straight into its part of the container.  Same bytes as the two-step route.
-std::vector<uint8_t> encode_records(int width, int height, int K, int block_size, const double* quant, const uint16_t* counts,
-                                    const uint32_t* choices) {
+namespace {
+void code_records(int width, int height, int K, int block_size, const double* quant, const uint16_t* counts, const uint32_t* choices,
+                  BitWriter& out, std::vector<BitWriter>& parts) {
     const size_t tiles = static_cast<size_t>((width + block_size - 1) / block_size) *
                          static_cast<size_t>((height + block_size - 1) / block_size);
-    BitWriter out;
     out.put(kMagic, 32);
     out.put(static_cast<uint32_t>(width), 32);
     out.put(static_cast<uint32_t>(height), 32);
@@ -770,7 +770,7 @@ std::vector<uint8_t> encode_records(int width, int height, int K, int block_size
     out.put(static_cast<uint8_t>(block_size), 8);
     for (int ch = 0; ch < 3; ++ch)
         for (int i = 0; i < K; ++i) out.put(static_cast<uint16_t>(quant[ch * K + i]), 16);    // :420 u16 of an integral double
-    std::vector<BitWriter> parts(static_cast<size_t>(6 * K + 1));
+    parts.assign(static_cast<size_t>(6 * K + 1), BitWriter());
     auto code_stream = [](const std::vector<uint16_t>& stream, bool dc, std::vector<uint16_t>& scratch, BitWriter& w) {
         const std::vector<uint16_t>* src = &stream;
         if (dc) {
@@ -810,9 +810,74 @@ std::vector<uint8_t> encode_records(int width, int height, int K, int block_size
         code_stream(d, false, scratch, parts[static_cast<size_t>(index + 1)]);
         code_stream(c, i == 0, scratch, parts[static_cast<size_t>(index + 2)]);   // DC: the step-0 coefficients (:428-446)
     });
+}
+
+// Concatenate head and parts bit-wise into big-endian bytes in a malloc'ed buffer.  Every part knows its bit offset, so
+// the parts are shifted into place in parallel; only the two words a part may share with its neighbours are merged
+// with atomic ORs (into words cleared beforehand), everything in between is a plain store.
+uint8_t* concat_malloc(const BitWriter& head, const std::vector<BitWriter>& parts, size_t* nbytes) {
+    std::vector<size_t> offset(parts.size() + 1);
+    size_t total = head.bit_size();
+    for (size_t p = 0; p < parts.size(); ++p) {
+        offset[p] = total;
+        total += parts[p].bit_size();
+    }
+    offset[parts.size()] = total;
+    const size_t nwords = (total + 63) / 64;
+    uint64_t* dst = static_cast<uint64_t*>(std::malloc((nwords ? nwords : 1) * sizeof(uint64_t)));
+    if (!dst) return nullptr;
+    auto place = [dst](const BitWriter& w, size_t bit_offset) {
+        const size_t nbits = w.bit_size();
+        if (nbits == 0) return;
+        const uint64_t* src = w.words();
+        const size_t src_words = (nbits + 63) / 64;
+        const size_t w0 = bit_offset >> 6, last = (bit_offset + nbits - 1) >> 6;
+        const int shift = static_cast<int>(bit_offset & 63);
+        for (size_t d = w0; d <= last; ++d) {                   // destination word d = source bits [64(d-w0) - shift, +64)
+            const size_t i = d - w0;
+            uint64_t v = 0;
+            if (shift == 0) v = i < src_words ? src[i] : 0;
+            else {
+                if (i < src_words) v |= src[i] >> shift;
+                if (i >= 1 && i - 1 < src_words) v |= src[i - 1] << (64 - shift);
+            }
+            const uint64_t be = __builtin_bswap64(v);            // MSB-first bit order = big-endian bytes
+            if (d == w0 || d == last) __atomic_fetch_or(&dst[d], be, __ATOMIC_RELAXED);
+            else dst[d] = be;
+        }
+    };
+    // clear the words that can be shared between neighbours (first and last word of every piece)
+    auto clear_ends = [dst](size_t bit_offset, size_t nbits) {
+        if (nbits == 0) return;
+        dst[bit_offset >> 6] = 0;
+        dst[(bit_offset + nbits - 1) >> 6] = 0;
+    };
+    clear_ends(0, head.bit_size());
+    for (size_t p = 0; p < parts.size(); ++p) clear_ends(offset[p], parts[p].bit_size());
+    place(head, 0);
+    parallel_for(static_cast<int>(parts.size()), [&](int p) { place(parts[static_cast<size_t>(p)], offset[static_cast<size_t>(p)]); });
+    *nbytes = (total + 7) / 8;
+    return reinterpret_cast<uint8_t*>(dst);
+}
+}  // namespace
+
+std::vector<uint8_t> encode_records(int width, int height, int K, int block_size, const double* quant, const uint16_t* counts,
+                                    const uint32_t* choices) {
+    BitWriter out;
+    std::vector<BitWriter> parts;
+    code_records(width, height, K, block_size, quant, counts, choices, out, parts);
     for (const BitWriter& w : parts) out.append(w);
     return out.bytes();
 }
+
+uint8_t* encode_records_malloc(int width, int height, int K, int block_size, const double* quant, const uint16_t* counts,
+                               const uint32_t* choices, size_t* nbytes) {
+    BitWriter head;
+    std::vector<BitWriter> parts;
+    code_records(width, height, K, block_size, quant, counts, choices, head, parts);
+    return concat_malloc(head, parts, nbytes);
+}
+
 
 bool read_compressed(const uint8_t* bytes, size_t nbytes, Streams& s) {
     BitReader in(bytes, nbytes);

@@ -20,6 +20,7 @@ public:
     // put(code_of[s], length_of[s]) for every s in data[0..n), through a register accumulator (lengths 1..32)
     void put_codes(const uint16_t* data, size_t n, const uint32_t* code_of, const uint8_t* length_of, size_t total_bits);
     size_t bit_size() const { return nbits_; }
+    const uint64_t* words() const { return words_.data(); }   // MSB-first, the last word zero-padded
     std::vector<uint8_t> bytes() const;             // zero-padded to a whole byte (BitBuffer::Save)
 private:
     std::vector<uint64_t> words_;
@@ -77,6 +78,9 @@ Streams assemble_streams(int width, int height, int K, int block_size, const dou
 // assemble_streams + write_compressed without the intermediate streams (what mpc_assemble_streams / mpc_encode_image use)
 std::vector<uint8_t> encode_records(int width, int height, int K, int block_size, const double* quant /*[3*K]*/,
                                     const uint16_t* counts, const uint32_t* choices);
+// the same into a malloc'ed buffer (release with free); nullptr = out of memory
+uint8_t* encode_records_malloc(int width, int height, int K, int block_size, const double* quant, const uint16_t* counts,
+                               const uint32_t* choices, size_t* nbytes);
 
 // Inverse of assemble_streams: per-tile records in the reference's visiting order.  counts[3*tiles],
 // choices[3*tiles*K] (deltaId | intCoeff << 16, zero beyond count).  false = streams inconsistent with `lengths`.

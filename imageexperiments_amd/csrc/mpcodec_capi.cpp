@@ -640,8 +640,7 @@ mpc_status mpc_assemble_streams(int width, int height, int K, int block_size, co
                                 const uint16_t* counts, const mpc_basis_choice* choices, uint8_t** bytes, size_t* nbytes) {
     if (!quant || !counts || !choices || !bytes || !nbytes || K < 1 || K > MPC_MAX_K || block_size < 1 || width < 1 || height < 1)
         return fail(MPC_ERR_ARGUMENT, "bad argument");
-    *bytes = give_bytes(mpc::encode_records(width, height, K, block_size, quant, counts, reinterpret_cast<const uint32_t*>(choices)),
-                        nbytes);
+    *bytes = mpc::encode_records_malloc(width, height, K, block_size, quant, counts, reinterpret_cast<const uint32_t*>(choices), nbytes);
     return *bytes ? MPC_OK : fail(MPC_ERR_ALLOC, "out of memory");
 }
 
@@ -795,19 +794,19 @@ mpc_status mpc_encode_images(mpc_context* c, const uint8_t* const* rgb_frames, i
     HIP_TRY(ensure_workspace(c, static_cast<long long>(n_tc)) == MPC_OK ? hipSuccess : hipErrorOutOfMemory);
     const double* q = quant ? quant : c->quant.data();
     struct Pending {
-        std::future<std::vector<uint8_t>> result;
+        std::future<std::pair<uint8_t*, size_t>> result;     // malloc'ed container, or {nullptr, 0}
         int frame = -1;
     } pending[2];
     mpc_status st = MPC_OK;
     auto collect = [&](Pending& p) {
         if (p.frame < 0) return;
-        std::vector<uint8_t> blob = p.result.get();
+        const std::pair<uint8_t*, size_t> blob = p.result.get();
+        if (st == MPC_OK && !blob.first) st = fail(MPC_ERR_HIP, "record download or container allocation failed");
         if (st == MPC_OK) {
-            if (blob.empty()) st = fail(MPC_ERR_HIP, "record download failed");
-            else {
-                bytes[p.frame] = give_bytes(blob, &nbytes[p.frame]);
-                if (!bytes[p.frame]) st = fail(MPC_ERR_ALLOC, "out of memory");
-            }
+            bytes[p.frame] = blob.first;
+            nbytes[p.frame] = blob.second;
+        } else {
+            std::free(blob.first);
         }
         p.frame = -1;
     };
@@ -849,9 +848,11 @@ mpc_status mpc_encode_images(mpc_context* c, const uint8_t* const* rgb_frames, i
         used[sl] = true;
         const int K = c->K, bs = c->block_size, device = c->device;
         slot.frame = f;
-        slot.result = std::async(std::launch::async, [=]() -> std::vector<uint8_t> {
-            if (hipSetDevice(device) != hipSuccess || hipEventSynchronize(ev_down) != hipSuccess) return {};
-            return mpc::encode_records(width, height, K, bs, q, counts, reinterpret_cast<const uint32_t*>(choices));
+        slot.result = std::async(std::launch::async, [=]() -> std::pair<uint8_t*, size_t> {
+            if (hipSetDevice(device) != hipSuccess || hipEventSynchronize(ev_down) != hipSuccess) return {nullptr, 0};
+            size_t n = 0;
+            uint8_t* blob = mpc::encode_records_malloc(width, height, K, bs, q, counts, reinterpret_cast<const uint32_t*>(choices), &n);
+            return {blob, n};
         });
     }
 #undef MPC_SEQ_TRY
