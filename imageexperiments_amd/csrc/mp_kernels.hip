@@ -552,17 +552,18 @@ __device__ __forceinline__ double load_b_global(bf16x8 (&hi)[2], bf16x8 (&lo)[2]
 // runner-up of the whole tile-channel stays below the threshold, the single survivor is known after pass 1 and the
 // second MFMA pass is not needed for it.
 struct TopTwo {
-    float m1 = 0.0f, m2 = 0.0f;
+    float m1 = 0.0f, m2 = 0.0f;                        // m1 >= m2 throughout
+    float sum = 0.0f;                                  // of every |value| seen: a NaN or an infinity poisons it
     int row = -1;
-    bool odd = false;                                  // saw a NaN or an infinity: leave it to pass 2
+    // five VALU instructions per value (this runs 4 x 576 times per tile-channel group and step): v_cmp + v_cndmask for
+    // the row, v_med3 (the middle of {m1, m2, a} is the new runner-up), v_max, v_add
     __device__ __forceinline__ void see(float value, int r)
     {
         const float a = fabsf(value);
-        const bool gt1 = a > m1, gt2 = a > m2;
-        m2 = gt1 ? m1 : (gt2 ? a : m2);
-        row = gt1 ? r : row;
-        m1 = gt1 ? a : m1;
-        odd = odd || !(a <= 3.4028234663852886e38f);
+        row = a > m1 ? r : row;
+        m2 = __builtin_amdgcn_fmed3f(m1, m2, a);
+        m1 = fmaxf(m1, a);
+        sum += a;
     }
     // fold in the three other lanes that hold rows of the same tile-channel: top = its largest approximation, second =
     // its runner-up (a tie for the top counts as a runner-up), mine = this lane owns the unique top row
@@ -579,7 +580,7 @@ struct TopTwo {
         rest = fmaxf(rest, __shfl_xor(rest, 32));
         second = n_top > 1 ? top : rest;
         mine = at_top && n_top == 1;
-        int o = odd ? 1 : 0;
+        int o = !(sum <= 3.4028234663852886e38f) ? 1 : 0;          // saw a NaN or an infinity (or overflowed): leave it to pass 2
         o |= __shfl_xor(o, 16);
         o |= __shfl_xor(o, 32);
         any_odd = o != 0;
