@@ -96,7 +96,7 @@ struct mpc_context {
 };
 
 namespace {
-constexpr long long kMaxBatchDefault = 3LL * 262144;   // tile-channels in flight per call (the workspaces are sized for it)
+constexpr long long kMaxBatchDefault = 3LL * 524288;   // tile-channels in flight per call (an 8K frame in one go; ~1.5 GB of workspace)
 
 // tuning overrides for experiments (results never depend on them)
 int env_int(const char* name, int fallback) {
@@ -128,11 +128,12 @@ mpc::DictDevice dict_device(const mpc_context* c) {
 // grow-only workspaces; allocation synchronises the device, so callers that must not (graph capture)
 // call mpc_reserve() first
 // how many sub-batches of a call run concurrently (measured on MI355X: 2 for a 1080p frame, 3 from ~300k
-// tile-channels up; 4 loses again)
+// tile-channels up, 4 for an 8K frame)
 int pipes_for(long long tile_channels) {
     const int forced = env_int("MPC_PIPES", 0);
     if (forced > 0) return std::min(forced, 4);
     if (tile_channels <= 3 * 4096) return 1;              // do not split what cannot fill the machine
+    if (tile_channels >= 1200000) return 4;               // an 8K frame
     return tile_channels >= 300000 ? 3 : 2;
 }
 
