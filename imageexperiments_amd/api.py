@@ -206,12 +206,12 @@ def read_compressed(blob):
         L.mpc_streams_free(h)
 
 
-def decode_image(blob, ctx=None):
-    """compressed::decodeImage (CompressedImage.h:75) -> uint8 [H,W,3]."""
+def decode_image(blob, ctx):
+    """compressed::decodeImage (CompressedImage.h:75) -> uint8 [H,W,3]; reconstructed on ctx's device (no host path)."""
     L = load_library()
     buf = np.frombuffer(bytes(blob), np.uint8)
     out, W, H = _u8p(), C.c_int(), C.c_int()
-    _check(L.mpc_decode_image(ctx.h if ctx is not None else None, buf.ctypes.data_as(_u8p), buf.size, C.byref(out),
+    _check(L.mpc_decode_image(ctx.h, buf.ctypes.data_as(_u8p), buf.size, C.byref(out),
                               C.byref(W), C.byref(H)))
     img = np.ctypeslib.as_array(out, shape=(H.value, W.value, 3)).copy()
     L.mpc_free(C.cast(out, C.c_void_p))

@@ -868,22 +868,17 @@ mpc_status mpc_encode_images(mpc_context* c, const uint8_t* const* rgb_frames, i
     return st;
 }
 
-// FromCoeffsDynamic + RGBFromYUV for whole tiles on the device
-mpc_status mpc_decode_tiles_device(mpc_context* c, const uint16_t* d_counts, const mpc_basis_choice* d_choices,
-                                   const double* quant, int width, int height, uint8_t* d_rgb, void* stream) {
-    if (!c || !d_counts || !d_choices || !d_rgb) return fail(MPC_ERR_ARGUMENT, "null argument");
-    if (c->device < 0) return fail(MPC_ERR_NO_DEVICE, "context was created without a device");
-    if (width < 1 || height < 1) return fail(MPC_ERR_ARGUMENT, "bad geometry");
+// FromCoeffsDynamic + RGBFromYUV for whole tiles on the device; d_quant: [3][K] doubles on the device
+static mpc_status decode_tiles_on_device(mpc_context* c, const uint16_t* d_counts, const uint32_t* d_choices, const double* d_quant,
+                                         int K, int width, int height, uint8_t* d_rgb, void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
-    HIP_TRY(hipSetDevice(c->device));
     if (!c->d_flag) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_flag), sizeof(int)));
-    if (quant) HIP_TRY(hipMemcpyAsync(c->d_quant, quant, 3 * sizeof(double) * c->K, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemsetAsync(c->d_flag, 0, sizeof(int), s));
     mpc::DecodeParams p{};
     p.counts = d_counts;
-    p.choices = reinterpret_cast<const uint32_t*>(d_choices);
-    p.quant = c->d_quant;
-    p.K = c->K;
+    p.choices = d_choices;
+    p.quant = d_quant;
+    p.K = K;
     p.width = width;
     p.height = height;
     p.tiles_x = (width + 7) / 8;
@@ -895,86 +890,78 @@ mpc_status mpc_decode_tiles_device(mpc_context* c, const uint16_t* d_counts, con
     return MPC_OK;
 }
 
-// compressed::decodeImage: container parsing on the host; tile reconstruction on the device when the context
-// has one and matches the stream's K / block size, on the host otherwise
+mpc_status mpc_decode_tiles_device(mpc_context* c, const uint16_t* d_counts, const mpc_basis_choice* d_choices,
+                                   const double* quant, int width, int height, uint8_t* d_rgb, void* stream) {
+    if (!c || !d_counts || !d_choices || !d_rgb) return fail(MPC_ERR_ARGUMENT, "null argument");
+    if (c->device < 0) return fail(MPC_ERR_NO_DEVICE, "context was created without a device");
+    if (width < 1 || height < 1) return fail(MPC_ERR_ARGUMENT, "bad geometry");
+    HIP_TRY(hipSetDevice(c->device));
+    if (quant)
+        HIP_TRY(hipMemcpyAsync(c->d_quant, quant, 3 * sizeof(double) * c->K, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)));
+    return decode_tiles_on_device(c, d_counts, reinterpret_cast<const uint32_t*>(d_choices), c->d_quant, c->K, width, height, d_rgb,
+                                  stream);
+}
+
+// compressed::decodeImage: container parsing on the host, tile reconstruction on the device.  The stream's own
+// K and quantisation table are used (they need not match the context's); there is no host reconstruction.
 mpc_status mpc_decode_image(const mpc_context* cc, const uint8_t* bytes, size_t nbytes, uint8_t** rgb, int* width, int* height) {
-    if (!bytes || !rgb || !width || !height) return fail(MPC_ERR_ARGUMENT, "null argument");
+    if (!cc || !bytes || !rgb || !width || !height) return fail(MPC_ERR_ARGUMENT, "null argument");
+    mpc_context* c = const_cast<mpc_context*>(cc);
+    if (c->device < 0) return fail(MPC_ERR_NO_DEVICE, "context was created without a device; there is no CPU fallback");
     mpc::Streams s;
     if (!mpc::read_compressed(bytes, nbytes, s)) return fail(MPC_ERR_BITSTREAM, "Invalid input data");
-    mpc_context* c = const_cast<mpc_context*>(cc);
-    if (c && c->device >= 0 && c->K == s.K && s.block_size == 8) {
-        // records via the context's pinned host buffer and device staging area (grow-only, shared with the encoder)
-        HIP_TRY(hipSetDevice(c->device));
-        const size_t n_tc = s.lengths.size();
-        auto up = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
-        const size_t counts_bytes = up(sizeof(uint16_t) * n_tc), choices_bytes = up(sizeof(uint32_t) * n_tc * s.K);
-        const size_t px = static_cast<size_t>(s.width) * s.height * 3;
-        if (counts_bytes + choices_bytes > c->host_stage_bytes) {
-            if (c->host_stage) (void)hipHostFree(c->host_stage);
-            c->host_stage = nullptr;
-            c->host_stage_bytes = 0;
-            const hipError_t ea = hipHostMalloc(&c->host_stage, counts_bytes + choices_bytes, hipHostMallocDefault);
-            if (ea != hipSuccess) return fail(MPC_ERR_ALLOC, "pinned staging: %s", hipGetErrorString(ea));
-            c->host_stage_bytes = counts_bytes + choices_bytes;
-        }
-        if (counts_bytes + choices_bytes + up(px) > c->stage_bytes) {
-            if (c->stage) (void)hipFree(c->stage);
-            c->stage = nullptr;
-            c->stage_bytes = 0;
-            const hipError_t ea = hipMalloc(&c->stage, counts_bytes + choices_bytes + up(px));
-            if (ea != hipSuccess) return fail(MPC_ERR_ALLOC, "device staging: %s", hipGetErrorString(ea));
-            c->stage_bytes = counts_bytes + choices_bytes + up(px);
-        }
-        uint16_t* counts = static_cast<uint16_t*>(c->host_stage);
-        uint32_t* choices = reinterpret_cast<uint32_t*>(static_cast<char*>(c->host_stage) + counts_bytes);
-        if (!mpc::disassemble_streams(s, counts, choices)) return fail(MPC_ERR_BITSTREAM, "Invalid bitstream");
-        std::vector<double> q(3 * static_cast<size_t>(s.K));
-        for (int ch = 0; ch < 3; ++ch)
-            for (int i = 0; i < s.K; ++i) q[ch * s.K + i] = static_cast<double>(s.quant[ch][i]);
-        char* dbase = static_cast<char*>(c->stage);
-        uint16_t* d_counts = reinterpret_cast<uint16_t*>(dbase);
-        uint32_t* d_choices = reinterpret_cast<uint32_t*>(dbase + counts_bytes);
-        uint8_t* d_rgb = reinterpret_cast<uint8_t*>(dbase + counts_bytes + choices_bytes);
-        hipError_t e = hipMemcpy(d_counts, counts, sizeof(uint16_t) * n_tc, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(d_choices, choices, sizeof(uint32_t) * n_tc * s.K, hipMemcpyHostToDevice);
-        mpc_status st = MPC_OK;
-        int flag = 0;
-        uint8_t* out = nullptr;
-        if (e == hipSuccess) {
-            // the context's device quant table is restored afterwards (decode uses the stream's header values)
-            st = mpc_decode_tiles_device(c, d_counts, reinterpret_cast<const mpc_basis_choice*>(d_choices), q.data(), s.width,
-                                         s.height, d_rgb, nullptr);
-            if (st == MPC_OK) e = hipDeviceSynchronize();
-            if (st == MPC_OK && e == hipSuccess) e = hipMemcpy(&flag, c->d_flag, sizeof(int), hipMemcpyDeviceToHost);
-            if (st == MPC_OK && e == hipSuccess) {
-                out = static_cast<uint8_t*>(std::malloc(px ? px : 1));
-                if (out) e = hipMemcpy(out, d_rgb, px, hipMemcpyDeviceToHost);
-            }
-            if (e == hipSuccess) e = hipMemcpy(c->d_quant, c->quant.data(), c->quant.size() * sizeof(double), hipMemcpyHostToDevice);
-        }
-        if (st != MPC_OK) { std::free(out); return st; }
-        if (e != hipSuccess) { std::free(out); return fail(MPC_ERR_HIP, "HIP failure: %s", hipGetErrorString(e)); }
-        if (!out) return fail(MPC_ERR_ALLOC, "out of memory");
-        if (flag) { std::free(out); return fail(MPC_ERR_BITSTREAM, "Invalid bitstream"); }
-        *rgb = out;
-        *width = s.width;
-        *height = s.height;
-        return MPC_OK;
+    if (s.block_size != c->block_size) return fail(MPC_ERR_ARGUMENT, "stream block size %d, context block size %d", s.block_size, c->block_size);
+    // records via the context's pinned host buffer and device staging area (grow-only, shared with the encoder)
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t n_tc = s.lengths.size();
+    auto up = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
+    const size_t counts_bytes = up(sizeof(uint16_t) * n_tc), choices_bytes = up(sizeof(uint32_t) * n_tc * s.K);
+    const size_t quant_bytes = up(sizeof(double) * 3 * s.K);
+    const size_t records_bytes = counts_bytes + choices_bytes + quant_bytes;
+    const size_t px = static_cast<size_t>(s.width) * s.height * 3;
+    if (records_bytes > c->host_stage_bytes) {
+        if (c->host_stage) (void)hipHostFree(c->host_stage);
+        c->host_stage = nullptr;
+        c->host_stage_bytes = 0;
+        const hipError_t ea = hipHostMalloc(&c->host_stage, records_bytes, hipHostMallocDefault);
+        if (ea != hipSuccess) return fail(MPC_ERR_ALLOC, "pinned staging: %s", hipGetErrorString(ea));
+        c->host_stage_bytes = records_bytes;
     }
-    mpc::Dictionary local;
-    const mpc::Dictionary* dict = nullptr;
-    if (c && c->block_size == s.block_size) dict = &c->dict;
-    else {
-        try { local = mpc::build_dictionary(s.block_size); } catch (const std::exception& e) { return fail(MPC_ERR_ARGUMENT, "%s", e.what()); }
-        dict = &local;
+    if (records_bytes + up(px) > c->stage_bytes) {
+        if (c->stage) (void)hipFree(c->stage);
+        c->stage = nullptr;
+        c->stage_bytes = 0;
+        const hipError_t ea = hipMalloc(&c->stage, records_bytes + up(px));
+        if (ea != hipSuccess) return fail(MPC_ERR_ALLOC, "device staging: %s", hipGetErrorString(ea));
+        c->stage_bytes = records_bytes + up(px);
     }
-    std::vector<uint8_t> out;
-    if (!mpc::decode_streams(*dict, s, out)) return fail(MPC_ERR_BITSTREAM, "Invalid bitstream");
-    size_t n = 0;
-    *rgb = give_bytes(out, &n);
+    char* hbase = static_cast<char*>(c->host_stage);
+    uint16_t* counts = reinterpret_cast<uint16_t*>(hbase);
+    uint32_t* choices = reinterpret_cast<uint32_t*>(hbase + counts_bytes);
+    double* q = reinterpret_cast<double*>(hbase + counts_bytes + choices_bytes);
+    if (!mpc::disassemble_streams(s, counts, choices)) return fail(MPC_ERR_BITSTREAM, "Invalid bitstream");
+    for (int ch = 0; ch < 3; ++ch)
+        for (int i = 0; i < s.K; ++i) q[ch * s.K + i] = static_cast<double>(s.quant[ch][i]);
+    char* dbase = static_cast<char*>(c->stage);
+    uint16_t* d_counts = reinterpret_cast<uint16_t*>(dbase);
+    uint32_t* d_choices = reinterpret_cast<uint32_t*>(dbase + counts_bytes);
+    double* d_q = reinterpret_cast<double*>(dbase + counts_bytes + choices_bytes);
+    uint8_t* d_rgb = reinterpret_cast<uint8_t*>(dbase + records_bytes);
+    HIP_TRY(hipMemcpy(dbase, hbase, records_bytes, hipMemcpyHostToDevice));
+    const mpc_status st = decode_tiles_on_device(c, d_counts, d_choices, d_q, s.K, s.width, s.height, d_rgb, nullptr);
+    if (st != MPC_OK) return st;
+    HIP_TRY(hipDeviceSynchronize());
+    int flag = 0;
+    HIP_TRY(hipMemcpy(&flag, c->d_flag, sizeof(int), hipMemcpyDeviceToHost));
+    if (flag) return fail(MPC_ERR_BITSTREAM, "Invalid bitstream");
+    uint8_t* out = static_cast<uint8_t*>(std::malloc(px ? px : 1));
+    if (!out) return fail(MPC_ERR_ALLOC, "out of memory");
+    const hipError_t e = hipMemcpy(out, d_rgb, px, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { std::free(out); return fail(MPC_ERR_HIP, "HIP failure: %s", hipGetErrorString(e)); }
+    *rgb = out;
     *width = s.width;
     *height = s.height;
-    return *rgb ? MPC_OK : fail(MPC_ERR_ALLOC, "out of memory");
+    return MPC_OK;
 }
 
 double mpc_psnr(const uint8_t* original, const uint8_t* decoded, int width, int height) {

@@ -199,9 +199,10 @@ mpc_status mpc_encode_images(mpc_context* ctx, const uint8_t* const* rgb_frames,
 mpc_status mpc_decode_tiles_device(mpc_context* ctx, const uint16_t* d_counts, const mpc_basis_choice* d_choices,
                                    const double* quant, int width, int height, uint8_t* d_rgb, void* stream);
 
-/* compressed::decodeImage (CompressedImage.h:75).  The container is parsed on the host; the tiles are
- * reconstructed on the device when ctx has one and matches the stream's K (block size 8), otherwise on the host;
- * ctx may be NULL (host, the dictionary is then rebuilt, ~1 s). */
+/* compressed::decodeImage (CompressedImage.h:75).  The container is parsed on the host and the tiles are
+ * reconstructed on ctx's device with the K and quantisation tables the stream carries (they need not equal the
+ * context's; the block size must).  A context without a device gets MPC_ERR_NO_DEVICE: there is no host
+ * reconstruction. */
 mpc_status mpc_decode_image(const mpc_context* ctx, const uint8_t* bytes, size_t nbytes, uint8_t** rgb, int* width,
                             int* height);
 

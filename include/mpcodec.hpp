@@ -158,11 +158,19 @@ inline std::vector<std::vector<uint8_t>> encodeImages(const std::vector<const im
     return out;
 }
 
+// The reference builds a context from the stream header on every call (CompressedImage.cpp:783-790).  Here any
+// device context of block size 8 decodes any stream (K and the tables come from the stream); without an explicit
+// one a process-wide context on device 0 is created on first use.  Reconstruction runs on the device only.
 inline std::unique_ptr<img::image<img::rgb>> decodeImage(const uint8_t bytes[], size_t byteSize,
                                                          const CompressionContext* context = nullptr) {
+    const mpc_context* handle = context ? context->handle : nullptr;
+    if (!handle) {
+        static const std::unique_ptr<CompressionContext> decoder = createCompressionContext(32, 8, 3.5, 0);
+        handle = decoder->handle;
+    }
     uint8_t* rgb = nullptr;
     int w = 0, h = 0;
-    detail::check(mpc_decode_image(context ? context->handle : nullptr, bytes, byteSize, &rgb, &w, &h));
+    detail::check(mpc_decode_image(handle, bytes, byteSize, &rgb, &w, &h));
     std::unique_ptr<img::image<img::rgb>> imgOut =
         std::make_unique<img::image<img::rgb>>(static_cast<size_t>(w), static_cast<size_t>(h), false);
     std::memcpy(static_cast<void*>(imgOut->data), rgb, static_cast<size_t>(w) * h * 3);

@@ -248,12 +248,16 @@ def test_device_decoder_equals_oracle_on_golden_mn(gpu, oracle, ctx32, mn_bytes)
     reference's own 16 Mpixel fixture pixel for pixel (and hence 39.07 dB vs the committed JPEG)."""
     import hashlib
     import imageexperiments_amd as ia
-    img = ia.decode_image(mn_bytes, ctx32)          # ctx32: K = 32 like the stream -> device path
+    img = ia.decode_image(mn_bytes, ctx32)
     ref = oracle.decode_image(mn_bytes)
     assert img.shape == (3264, 4928, 3)
     assert (img == ref).all()
     assert hashlib.sha256(img.tobytes()).hexdigest() == hashlib.sha256(ref.tobytes()).hexdigest()
-    # after decoding with the header's tables the context's own tables are back in place
+    # the stream's own K and tables are used: a context of another K decodes it to the same pixels
+    other = ia.create_compression_context(8, 8, 5.0, device=0)
+    assert (ia.decode_image(mn_bytes, other) == ref).all()
+    other.close()
+    # decoding leaves the context's own tables untouched
     rgb = oracle.synth_frame(64, 48, 1)
     assert ctx32.encode_image(rgb) == oracle.OracleContext(32, 8, 3.5).encode_image(rgb)
 
