@@ -101,6 +101,13 @@ def _bind_bitstream(L):
     L.mpc_encode_images.argtypes = [vp, C.POINTER(_u8p), C.c_int, C.c_int, C.c_int, _dp, C.POINTER(_u8p), C.POINTER(C.c_size_t)]
     L.mpc_decode_tiles_device.argtypes = [vp, vp, vp, _dp, C.c_int, C.c_int, vp, vp]
     L.mpc_decode_image.argtypes = [vp, _u8p, C.c_size_t, C.POINTER(_u8p), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.mpc_patch_stats_create.argtypes = [vp, C.c_uint, C.POINTER(vp)]
+    L.mpc_patch_stats_destroy.argtypes = [vp]
+    L.mpc_patch_stats_destroy.restype = None
+    L.mpc_patch_stats_add_image.argtypes = [vp, _u8p, C.c_int, C.c_int, C.c_int]
+    L.mpc_patch_stats_read.argtypes = [vp, _dp]
+    L.mpc_patch_stats_report.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t)]
+    L.mpc_format_double.argtypes = [C.c_double, C.c_char_p, C.c_int]
     L.mpc_psnr.argtypes = [_u8p, _u8p, C.c_int, C.c_int]
     L.mpc_psnr.restype = C.c_double
 
@@ -224,6 +231,54 @@ def calculate_psnr(original, decoded):
     a = np.ascontiguousarray(original, np.uint8)
     b = np.ascontiguousarray(decoded, np.uint8)
     return L.mpc_psnr(a.ctypes.data_as(_u8p), b.ctypes.data_as(_u8p), a.shape[1], a.shape[0])
+
+
+def format_double(v):
+    """std::format("{}", double) as the reference's reports print numbers (shortest round-trip text)."""
+    buf = C.create_string_buffer(64)
+    n = load_library().mpc_format_double(float(v), buf, 64)
+    if n < 0:
+        raise ValueError("buffer too small")
+    return buf.value.decode()
+
+
+class PatchStatistics:
+    """The "-s" mode of Compression.cpp:200-302: random patches of every image through CalcMPDynamic with all
+    quantisers 1.0 (on ctx's device), Welford statistics of intCoeff / deltaId per step, and the text report."""
+
+    def __init__(self, ctx, seed):
+        self.L = load_library()
+        self.ctx = ctx
+        self.h = None
+        h = C.c_void_p()
+        _check(self.L.mpc_patch_stats_create(ctx.h, int(seed), C.byref(h)))
+        self.h = h
+
+    def add_image(self, rgb, patches):
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        H, W, _ = rgb.shape
+        _check(self.L.mpc_patch_stats_add_image(self.h, rgb.ctypes.data_as(_u8p), W, H, int(patches)))
+
+    def read(self):
+        """[3 channels][intCoeff, deltaId][K steps][N, min, max, mean, sumSq]"""
+        out = np.zeros((3, 2, self.ctx.K, 5), np.float64)
+        _check(self.L.mpc_patch_stats_read(self.h, out.ctypes.data_as(_dp)))
+        return out
+
+    def report(self):
+        text, n = C.c_char_p(), C.c_size_t()
+        _check(self.L.mpc_patch_stats_report(self.h, C.byref(text), C.byref(n)))
+        out = C.string_at(text, n.value).decode()
+        self.L.mpc_free(C.cast(text, C.c_void_p))
+        return out
+
+    def close(self):
+        if self.h:
+            self.L.mpc_patch_stats_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
 
 
 def _check(st):

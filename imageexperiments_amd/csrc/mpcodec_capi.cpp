@@ -18,6 +18,7 @@
 
 #include "host_bitstream.h"
 #include "host_codec.h"
+#include "host_stats.h"
 #include "host_dictionary.h"
 #include "mp_device.h"
 
@@ -962,6 +963,82 @@ mpc_status mpc_decode_image(const mpc_context* cc, const uint8_t* bytes, size_t 
     *width = s.width;
     *height = s.height;
     return MPC_OK;
+}
+
+// ---- "-s" patch statistics (Compression.cpp:200-302) ----
+struct mpc_patch_stats {
+    mpc_context* ctx;
+    mpc::PatchStats stats;
+    std::vector<uint8_t> mosaic;
+    std::vector<uint16_t> counts;
+    std::vector<uint32_t> choices;
+    mpc_patch_stats(mpc_context* c, unsigned seed) : ctx(c), stats(c->K, c->block_size, seed) {}
+};
+
+mpc_status mpc_patch_stats_create(mpc_context* c, unsigned seed, mpc_patch_stats** out) {
+    if (!c || !out) return fail(MPC_ERR_ARGUMENT, "null argument");
+    if (c->device < 0) return fail(MPC_ERR_NO_DEVICE, "context was created without a device; there is no CPU fallback");
+    try {
+        *out = new mpc_patch_stats(c, seed);
+    } catch (const std::bad_alloc&) { return fail(MPC_ERR_ALLOC, "out of memory"); }
+    return MPC_OK;
+}
+
+void mpc_patch_stats_destroy(mpc_patch_stats* s) { delete s; }
+
+mpc_status mpc_patch_stats_add_image(mpc_patch_stats* s, const uint8_t* rgb, int width, int height, int patches) {
+    if (!s || !rgb) return fail(MPC_ERR_ARGUMENT, "null argument");
+    const int bs = s->stats.block_size, K = s->stats.K;
+    if (width < bs || height < bs || patches <= 0) return MPC_OK;            // Compression.cpp:233-236
+    if (width == bs || height == bs) return fail(MPC_ERR_ARGUMENT, "image of exactly one block: rand() %% 0 in the reference");
+    std::vector<int> xs, ys;
+    s->stats.sample_origins(width, height, patches, xs, ys);
+    // the patches as the tiles of a one-tile-high mosaic: tile p = patch p (tile order tx*1 + 0)
+    const size_t row = static_cast<size_t>(patches) * bs * 3;
+    s->mosaic.resize(row * bs);
+    for (int p = 0; p < patches; ++p)
+        for (int dy = 0; dy < bs; ++dy)
+            std::memcpy(s->mosaic.data() + dy * row + static_cast<size_t>(p) * bs * 3,
+                        rgb + 3 * (static_cast<size_t>(ys[p] + dy) * width + xs[p]), static_cast<size_t>(bs) * 3);
+    s->counts.resize(static_cast<size_t>(patches) * 3);
+    s->choices.resize(static_cast<size_t>(patches) * 3 * K);
+    const std::vector<double> ones(3 * static_cast<size_t>(K), 1.0);          // Compression.cpp:221-225
+    const mpc_status st = mpc_encode_tiles(s->ctx, s->mosaic.data(), patches * bs, bs, row, 0, 1, ones.data(), s->counts.data(),
+                                           reinterpret_cast<mpc_basis_choice*>(s->choices.data()), nullptr, nullptr);
+    if (st != MPC_OK) return st;
+    s->stats.accumulate(s->counts.data(), s->choices.data(), patches);
+    return MPC_OK;
+}
+
+mpc_status mpc_patch_stats_read(const mpc_patch_stats* s, double* out) {
+    if (!s || !out) return fail(MPC_ERR_ARGUMENT, "null argument");
+    const int K = s->stats.K;
+    for (int ch = 0; ch < 3; ++ch)
+        for (int kind = 0; kind < 2; ++kind)
+            for (int i = 0; i < K; ++i) {
+                const mpc::RunningStat& r = kind == 0 ? s->stats.coeff[ch][i] : s->stats.select[ch][i];
+                double* o = out + ((static_cast<size_t>(ch) * 2 + kind) * K + i) * 5;
+                o[0] = r.N; o[1] = r.min; o[2] = r.max; o[3] = r.mean; o[4] = r.sumSq;
+            }
+    return MPC_OK;
+}
+
+mpc_status mpc_patch_stats_report(const mpc_patch_stats* s, char** text, size_t* nbytes) {
+    if (!s || !text || !nbytes) return fail(MPC_ERR_ARGUMENT, "null argument");
+    const std::string r = s->stats.report();
+    char* p = static_cast<char*>(std::malloc(r.size() + 1));
+    if (!p) return fail(MPC_ERR_ALLOC, "out of memory");
+    std::memcpy(p, r.c_str(), r.size() + 1);
+    *text = p;
+    *nbytes = r.size();
+    return MPC_OK;
+}
+
+int mpc_format_double(double v, char* buf, int cap) {
+    const std::string t = mpc::format_double(v);
+    if (!buf || cap <= static_cast<int>(t.size())) return -1;
+    std::memcpy(buf, t.c_str(), t.size() + 1);
+    return static_cast<int>(t.size());
 }
 
 double mpc_psnr(const uint8_t* original, const uint8_t* decoded, int width, int height) {

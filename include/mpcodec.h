@@ -206,6 +206,26 @@ mpc_status mpc_decode_tiles_device(mpc_context* ctx, const uint16_t* d_counts, c
 mpc_status mpc_decode_image(const mpc_context* ctx, const uint8_t* bytes, size_t nbytes, uint8_t** rgb, int* width,
                             int* height);
 
+/* ---- "-s" patch statistics, Compression.cpp:200-302 ----
+ * The reference seeds one std::mt19937, and for every image draws `patches` origins x = rand() % (width - bs),
+ * y = rand() % (height - bs), runs CalcMPDynamic on the Y, U and V patch with every quantiser 1.0 and feeds
+ * intCoeff and deltaId of steps 0..count-1 to math::Stat::update (Welford, SimpleMatrix/src/covariance.cpp:5-25);
+ * its text report is how Data/stats.txt and the variance tables s_varY/U/V (CompressedImage.cpp:17-122) were made.
+ * Here the patches of one image are encoded in one launch of the tile encoder on ctx's device; the statistics are
+ * updated on the host in the reference's order, so every double equals the reference's bit for bit. */
+typedef struct mpc_patch_stats mpc_patch_stats;
+mpc_status mpc_patch_stats_create(mpc_context* ctx, unsigned seed, mpc_patch_stats** out);
+void mpc_patch_stats_destroy(mpc_patch_stats* s);
+/* images narrower or lower than the block are skipped like Compression.cpp:233-236 (MPC_OK, nothing drawn);
+ * width or height == block size is MPC_ERR_ARGUMENT (the reference divides by zero there). */
+mpc_status mpc_patch_stats_add_image(mpc_patch_stats* s, const uint8_t* rgb, int width, int height, int patches);
+/* out[3][2][K][5]: channel Y,U,V x {intCoeff, deltaId} x step x {N, min, max, mean, sumSq} */
+mpc_status mpc_patch_stats_read(const mpc_patch_stats* s, double* out);
+/* the report of Compression.cpp:275-301 as '\n'-terminated lines; release with mpc_free */
+mpc_status mpc_patch_stats_report(const mpc_patch_stats* s, char** text, size_t* nbytes);
+/* std::format("{}", v) of one double (shortest round-trip text), NUL terminated into buf[cap]; returns the length */
+int mpc_format_double(double v, char* buf, int cap);
+
 /* compressed::calculatePSNR (CompressedImage.h:57) */
 double mpc_psnr(const uint8_t* original, const uint8_t* decoded, int width, int height);
 

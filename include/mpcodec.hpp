@@ -19,6 +19,7 @@
 #include <cstring>
 #include <memory>
 #include <stdexcept>
+#include <string>
 #include <vector>
 
 #include "mpcodec.h"
@@ -182,6 +183,31 @@ inline double calculatePSNR(const img::image<img::rgb>* original, const img::ima
     return mpc_psnr(reinterpret_cast<const uint8_t*>(original->data), reinterpret_cast<const uint8_t*>(decoded->data),
                     static_cast<int>(original->width()), static_cast<int>(original->height()));
 }
+
+// The "-s" mode of Compression.cpp:200-302 as an object: one generator for the whole file list, addImage per
+// file, report() = the text the reference writes to its output file.
+class PatchStatistics {
+public:
+    PatchStatistics(CompressionContext& context, unsigned seed) { detail::check(mpc_patch_stats_create(context.handle, seed, &handle_)); }
+    ~PatchStatistics() { mpc_patch_stats_destroy(handle_); }
+    PatchStatistics(const PatchStatistics&) = delete;
+    PatchStatistics& operator=(const PatchStatistics&) = delete;
+    void addImage(const img::image<img::rgb>* image, int patchesPerImage) {
+        detail::check(mpc_patch_stats_add_image(handle_, reinterpret_cast<const uint8_t*>(image->data),
+                                                static_cast<int>(image->width()), static_cast<int>(image->height()), patchesPerImage));
+    }
+    std::string report() const {
+        char* text = nullptr;
+        size_t n = 0;
+        detail::check(mpc_patch_stats_report(handle_, &text, &n));
+        std::string out(text, n);
+        mpc_free(text);
+        return out;
+    }
+
+private:
+    mpc_patch_stats* handle_ = nullptr;
+};
 
 }  // namespace compressed
 

@@ -189,6 +189,14 @@ double mpo_psnr(const uint8_t *a, const uint8_t *b, int W, int H);
 double mpo_variance_constant(int ch, int i);
 double mpo_decay_constant(int ch);
 
+/* "-s" patch statistics (Compression.cpp:200-302; Welford update SimpleMatrix/src/covariance.cpp:5-25).
+ * Parity unpinned beyond the pursuit itself: the images Data/stats.txt was made from are not in the reference tree. */
+typedef struct mpo_patch_stats mpo_patch_stats;
+mpo_patch_stats *mpo_patch_stats_create(int K, uint32_t seed);
+void mpo_patch_stats_destroy(mpo_patch_stats *p);
+void mpo_patch_stats_add_image(mpo_patch_stats *p, const mpo_ctx *c, const uint8_t *rgb, int W, int H, int patches);
+void mpo_patch_stats_read(const mpo_patch_stats *p, double *out /* [3][2][K][5]: N,min,max,mean,sumSq */);
+
 /* synthetic frame generator of BASELINE.md 3 (std::mt19937 restated) */
 void mpo_synth_frame(uint8_t *rgb, int W, int H, uint32_t seed);
 

@@ -327,6 +327,76 @@ void mpo_synth_frame(uint8_t *rgb, int W, int H, uint32_t seed)
         }
 }
 
+/* ---- "-s" patch statistics: Compression.cpp:200-302, math::Stat SimpleMatrix/src/covariance.cpp:5-25 ---- */
+typedef struct { double N, min, max, mean, sumSq; } mpo_stat;
+struct mpo_patch_stats {
+    mt_state rng;
+    int K;
+    mpo_stat s[3][2][MPO_MAX_K];      /* [channel][0 = intCoeff, 1 = deltaId][step] */
+};
+
+static void stat_update(mpo_stat *s, double val)                   /* covariance.cpp:5-21 */
+{
+    if (s->N == 0) {
+        s->N = 1.0; s->min = val; s->max = val; s->mean = val; s->sumSq = 0.0;
+    } else {
+        if (val < s->min) s->min = val;
+        if (val > s->max) s->max = val;
+        s->N += 1.0;
+        double delta = val - s->mean;
+        s->mean += delta / s->N;
+        double delta2 = val - s->mean;
+        s->sumSq += delta * delta2;
+    }
+}
+
+mpo_patch_stats *mpo_patch_stats_create(int K, uint32_t seed)      /* Compression.cpp:210-220 */
+{
+    mpo_patch_stats *p = (mpo_patch_stats *)calloc(1, sizeof *p);
+    if (!p) return NULL;
+    p->K = K;
+    mt_seed(&p->rng, seed);
+    return p;
+}
+
+void mpo_patch_stats_destroy(mpo_patch_stats *p) { free(p); }
+
+/* one image of the loop at Compression.cpp:226-273; all quantisers 1.0 (:221-225) */
+void mpo_patch_stats_add_image(mpo_patch_stats *p, const mpo_ctx *c, const uint8_t *rgb, int W, int H, int patches)
+{
+    const int bs = c->bs, N = c->N, K = p->K;
+    if (W < bs || H < bs) return;                                  /* :233-236 */
+    double quant[MPO_MAX_K];
+    for (int i = 0; i < K; i++) quant[i] = 1.0;
+    double *yuv = (double *)malloc(sizeof(double) * 3 * N);
+    uint16_t delta[MPO_MAX_K], coef[MPO_MAX_K];
+    for (int reps = 0; reps < patches; reps++) {
+        int x = (int)(mt_next(&p->rng) % (uint32_t)(W - bs));      /* :238 */
+        int y = (int)(mt_next(&p->rng) % (uint32_t)(H - bs));      /* :239 */
+        mpo_gather_tile(rgb, W, H, bs, x, y, yuv);                 /* :240-248: patch[offx + offy*bs], always inside */
+        for (int ch = 0; ch < 3; ch++) {                           /* :249-269 */
+            int count = mpo_calc_mp(c, ch, quant, yuv + ch * N, delta, coef, NULL, NULL);
+            for (int i = 0; i < count; i++) {
+                stat_update(&p->s[ch][0][i], (double)coef[i]);
+                stat_update(&p->s[ch][1][i], (double)delta[i]);
+            }
+        }
+    }
+    free(yuv);
+}
+
+/* out[3][2][K][5] = N, min, max, mean, sumSq */
+void mpo_patch_stats_read(const mpo_patch_stats *p, double *out)
+{
+    for (int ch = 0; ch < 3; ch++)
+        for (int kind = 0; kind < 2; kind++)
+            for (int i = 0; i < p->K; i++) {
+                const mpo_stat *s = &p->s[ch][kind][i];
+                double *o = out + (((size_t)ch * 2 + kind) * p->K + i) * 5;
+                o[0] = s->N; o[1] = s->min; o[2] = s->max; o[3] = s->mean; o[4] = s->sumSq;
+            }
+}
+
 /* accessor for tests: the variance constants above vs Data/stats.txt */
 double mpo_variance_constant(int ch, int i) { return VAR[ch][i]; }
 double mpo_decay_constant(int ch) { return DECAY[ch]; }

@@ -87,6 +87,11 @@ def lib():
         L.mpo_psnr.restype = C.c_double
         L.mpo_psnr.argtypes = [u8p, u8p, C.c_int, C.c_int]
         L.mpo_synth_frame.argtypes = [u8p, C.c_int, C.c_int, C.c_uint32]
+        L.mpo_patch_stats_create.restype = C.c_void_p
+        L.mpo_patch_stats_create.argtypes = [C.c_int, C.c_uint32]
+        L.mpo_patch_stats_destroy.argtypes = [C.c_void_p]
+        L.mpo_patch_stats_add_image.argtypes = [C.c_void_p, C.POINTER(Ctx), u8p, C.c_int, C.c_int, C.c_int]
+        L.mpo_patch_stats_read.argtypes = [C.c_void_p, dp]
         L.mpo_yuv_from_rgb.argtypes = [C.c_uint8, C.c_uint8, C.c_uint8, dp, dp, dp]
         L.mpo_rgb_from_yuv.argtypes = [C.c_double, C.c_double, C.c_double, u8p, u8p, u8p]
         L.mpo_bits_init.argtypes = [C.POINTER(Bits)]
@@ -244,6 +249,32 @@ class OracleContext:
 
 _libc = C.CDLL(None)
 _libc.free.argtypes = [C.c_void_p]
+
+
+class OraclePatchStats:
+    """The "-s" mode of Compression.cpp:200-302 (one std::mt19937, Welford statistics per step)."""
+
+    def __init__(self, ctx, seed):
+        self.ctx = ctx
+        self.p = ctx.L.mpo_patch_stats_create(ctx.K, int(seed))
+
+    def add_image(self, rgb, patches):
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        H, W, _ = rgb.shape
+        self.ctx.L.mpo_patch_stats_add_image(self.p, self.ctx.p, _u8p(rgb), W, H, int(patches))
+
+    def read(self):
+        out = np.zeros((3, 2, self.ctx.K, 5), np.float64)
+        self.ctx.L.mpo_patch_stats_read(self.p, _dp(out))
+        return out
+
+    def close(self):
+        if self.p:
+            self.ctx.L.mpo_patch_stats_destroy(self.p)
+            self.p = None
+
+    def __del__(self):
+        self.close()
 
 
 def _libc_free(p):
