@@ -71,7 +71,9 @@ struct mpc_context {
     size_t host_stage_bytes = 0;
     // mpc_encode_images: upload / compute / download streams and per-slot events (upload done, pursuit done, download done)
     hipStream_t seq_up = nullptr, seq_compute = nullptr, seq_down = nullptr;
-    hipEvent_t seq_events[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    static constexpr int kSeqSlots = 4;              // frames in flight in mpc_encode_images
+    int pipes_cap = 0;                               // > 0: at most this many concurrent sub-batches per call
+    hipEvent_t seq_events[kSeqSlots][3] = {};
     // The pursuit of a call is cut into sub-batches that run on `pipes` internal streams, each with its own
     // workspace: the latency-bound bookkeeping kernels of one sub-batch (finish, update, bucket, fill) overlap
     // the machine-filling sweeps of the other.  Fork/join with events on the caller's stream: still no host
@@ -130,16 +132,17 @@ mpc::DictDevice dict_device(const mpc_context* c) {
 // call mpc_reserve() first
 // how many sub-batches of a call run concurrently (measured on MI355X: 2 for a 1080p frame, 3 from ~300k
 // tile-channels up, 4 for an 8K frame)
-int pipes_for(long long tile_channels) {
+int pipes_for(const mpc_context* c, long long tile_channels) {
     const int forced = env_int("MPC_PIPES", 0);
     if (forced > 0) return std::min(forced, 4);
     if (tile_channels <= 3 * 4096) return 1;              // do not split what cannot fill the machine
-    if (tile_channels >= 1200000) return 4;               // an 8K frame
-    return tile_channels >= 300000 ? 3 : 2;
+    int pipes = tile_channels >= 1200000 ? 4 : (tile_channels >= 300000 ? 3 : 2);      // 4: an 8K frame
+    if (c->pipes_cap > 0 && pipes > c->pipes_cap) pipes = c->pipes_cap;
+    return pipes;
 }
 
 mpc_status ensure_workspace(mpc_context* c, long long tile_channels) {
-    const int want_pipes = pipes_for(tile_channels);
+    const int want_pipes = pipes_for(c, tile_channels);
     const long long kMaxBatch = max_batch();
     long long total = tile_channels < kMaxBatch ? tile_channels : kMaxBatch;
     long long cap = (total + want_pipes - 1) / want_pipes;
@@ -184,7 +187,7 @@ mpc_status run_pursuit(mpc_context* c, const mpc::FrameInput& in, const mpc::Out
     const mpc::DictDevice dict = dict_device(c);
     hipStream_t caller = static_cast<hipStream_t>(stream);
     // sub-batch size: an even share per pipe (whole units), at most the workspace capacity
-    const long long npipes = pipes_for(total_tc);
+    const long long npipes = pipes_for(c, total_tc);
     long long share = (total_tc + npipes - 1) / npipes;
     share = (share + 767) / 768 * 768;
     if (share > c->ws_cap) share = c->ws_cap;
@@ -763,28 +766,30 @@ mpc_status mpc_encode_images(mpc_context* c, const uint8_t* const* rgb_frames, i
     const size_t tiles = static_cast<size_t>((width + 7) / 8) * tiles_y;
     const size_t n_tc = tiles * 3;
     HIP_TRY(hipSetDevice(c->device));
-    // Three stages, two slots: while the device encodes frame f (compute stream), frame f+1 is uploaded (upload stream;
-    // pageable memory, so the call blocks this thread, not the device), the records of frame f-1 travel to pinned host
-    // memory (download stream) and a worker codes them into their container.
+    // Three stages over kSeqSlots slots: while the device encodes frame f (compute stream), frame f+1 is uploaded
+    // (upload stream, via the slot's pinned image), the records of frame f-1 travel
+    // to pinned host memory (download stream) and workers code earlier frames into their containers.  This thread only
+    // waits for the entropy stage of frame f - kSeqSlots, so it stays ahead of the device.
     auto up = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
     const size_t img_bytes = static_cast<size_t>(3) * width * height;
     const size_t counts_bytes = up(sizeof(uint16_t) * n_tc), choices_bytes = up(sizeof(mpc_basis_choice) * n_tc * c->K);
-    const size_t host_slot = counts_bytes + choices_bytes, dev_slot = up(img_bytes) + host_slot;
-    if (2 * host_slot > c->host_stage_bytes) {
+    const size_t dev_slot = up(img_bytes) + counts_bytes + choices_bytes, host_slot = dev_slot;   // image | counts | choices
+    constexpr size_t S = mpc_context::kSeqSlots;
+    if (S * host_slot > c->host_stage_bytes) {
         if (c->host_stage) (void)hipHostFree(c->host_stage);
         c->host_stage = nullptr;
         c->host_stage_bytes = 0;
-        const hipError_t e = hipHostMalloc(&c->host_stage, 2 * host_slot, hipHostMallocDefault);
-        if (e != hipSuccess) return fail(MPC_ERR_ALLOC, "pinned staging of %zu bytes: %s", 2 * host_slot, hipGetErrorString(e));
-        c->host_stage_bytes = 2 * host_slot;
+        const hipError_t e = hipHostMalloc(&c->host_stage, S * host_slot, hipHostMallocDefault);
+        if (e != hipSuccess) return fail(MPC_ERR_ALLOC, "pinned staging of %zu bytes: %s", S * host_slot, hipGetErrorString(e));
+        c->host_stage_bytes = S * host_slot;
     }
-    if (2 * dev_slot > c->stage_bytes) {
+    if (S * dev_slot > c->stage_bytes) {
         if (c->stage) (void)hipFree(c->stage);
         c->stage = nullptr;
         c->stage_bytes = 0;
-        const hipError_t e = hipMalloc(&c->stage, 2 * dev_slot);
-        if (e != hipSuccess) return fail(MPC_ERR_ALLOC, "device staging of %zu bytes: %s", 2 * dev_slot, hipGetErrorString(e));
-        c->stage_bytes = 2 * dev_slot;
+        const hipError_t e = hipMalloc(&c->stage, S * dev_slot);
+        if (e != hipSuccess) return fail(MPC_ERR_ALLOC, "device staging of %zu bytes: %s", S * dev_slot, hipGetErrorString(e));
+        c->stage_bytes = S * dev_slot;
     }
     if (!c->seq_up) {
         HIP_TRY(hipStreamCreateWithFlags(&c->seq_up, hipStreamNonBlocking));
@@ -793,12 +798,19 @@ mpc_status mpc_encode_images(mpc_context* c, const uint8_t* const* rgb_frames, i
         for (auto& slot : c->seq_events)
             for (hipEvent_t& e : slot) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
+    // with the upload and download streams busy next to the pursuit, two sub-batch streams per frame measured faster
+    // than the three or four a lone frame uses (the runtime multiplexes all streams onto four hardware queues)
+    struct PipesCap {
+        mpc_context* c;
+        explicit PipesCap(mpc_context* c_) : c(c_) { c->pipes_cap = 2; }
+        ~PipesCap() { c->pipes_cap = 0; }
+    } pipes_cap(c);
     HIP_TRY(ensure_workspace(c, static_cast<long long>(n_tc)) == MPC_OK ? hipSuccess : hipErrorOutOfMemory);
     const double* q = quant ? quant : c->quant.data();
     struct Pending {
         std::future<std::pair<uint8_t*, size_t>> result;     // malloc'ed container, or {nullptr, 0}
         int frame = -1;
-    } pending[2];
+    } pending[S];
     mpc_status st = MPC_OK;
     auto collect = [&](Pending& p) {
         if (p.frame < 0) return;
@@ -817,25 +829,41 @@ mpc_status mpc_encode_images(mpc_context* c, const uint8_t* const* rgb_frames, i
         const hipError_t e_ = (call);                                                             \
         if (e_ != hipSuccess) { st = fail(MPC_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); break; } \
     }
-    bool used[2] = {false, false};                                // the slot's events have been recorded at least once
+    bool used[S] = {};                                            // the slot's events have been recorded at least once
     for (int f = 0; f < n_frames && st == MPC_OK; ++f) {
-        const int sl = f & 1;
+        const int sl = f % static_cast<int>(S);
         Pending& slot = pending[sl];
-        collect(slot);                                            // frame f-2 has left this slot's pinned buffer
+        collect(slot);                                            // frame f-S has left this slot's pinned buffer
         if (st != MPC_OK) break;
         char* dbase = static_cast<char*>(c->stage) + static_cast<size_t>(sl) * dev_slot;
         uint8_t* d_rgb = reinterpret_cast<uint8_t*>(dbase);
         uint16_t* d_counts = reinterpret_cast<uint16_t*>(dbase + up(img_bytes));
         mpc_basis_choice* d_choices = reinterpret_cast<mpc_basis_choice*>(dbase + up(img_bytes) + counts_bytes);
         char* hbase = static_cast<char*>(c->host_stage) + static_cast<size_t>(sl) * host_slot;
-        uint16_t* counts = reinterpret_cast<uint16_t*>(hbase);
-        mpc_basis_choice* choices = reinterpret_cast<mpc_basis_choice*>(hbase + counts_bytes);
+        uint8_t* pinned_rgb = reinterpret_cast<uint8_t*>(hbase);
+        uint16_t* counts = reinterpret_cast<uint16_t*>(hbase + up(img_bytes));
+        mpc_basis_choice* choices = reinterpret_cast<mpc_basis_choice*>(hbase + up(img_bytes) + counts_bytes);
         hipEvent_t ev_up = c->seq_events[sl][0], ev_comp = c->seq_events[sl][1], ev_down = c->seq_events[sl][2];
-        // upload: the pursuit of frame f-2 must be done with this slot's image
+        // upload: the pursuit of frame f-S must be done with this slot's image
         if (used[sl]) MPC_SEQ_TRY(hipStreamWaitEvent(c->seq_up, ev_comp, 0));
-        MPC_SEQ_TRY(hipMemcpyAsync(d_rgb, rgb_frames[f], img_bytes, hipMemcpyHostToDevice, c->seq_up));
+        // the caller's frame is pageable: the runtime would stage it through one thread at a few GB/s while this
+        // thread waits; a few threads copy it into the slot's pinned image instead and the DMA runs asynchronously
+        {
+            constexpr int kCopiers = 4;
+            const size_t piece = ((img_bytes + kCopiers - 1) / kCopiers + 4095) & ~static_cast<size_t>(4095);
+            std::future<void> parts[kCopiers];
+            const uint8_t* src = rgb_frames[f];
+            for (int k = 1; k < kCopiers; ++k) {
+                const size_t lo = std::min(img_bytes, piece * k), hi = std::min(img_bytes, piece * (k + 1));
+                if (hi > lo) parts[k] = std::async(std::launch::async, [=] { std::memcpy(pinned_rgb + lo, src + lo, hi - lo); });
+            }
+            std::memcpy(pinned_rgb, src, std::min(img_bytes, piece));
+            for (int k = 1; k < kCopiers; ++k)
+                if (parts[k].valid()) parts[k].get();
+        }
+        MPC_SEQ_TRY(hipMemcpyAsync(d_rgb, pinned_rgb, img_bytes, hipMemcpyHostToDevice, c->seq_up));
         MPC_SEQ_TRY(hipEventRecord(ev_up, c->seq_up));
-        // compute: after the upload, and after frame f-2's records have left the device buffers
+        // compute: after the upload, and after frame f-S's records have left the device buffers
         MPC_SEQ_TRY(hipStreamWaitEvent(c->seq_compute, ev_up, 0));
         if (used[sl]) MPC_SEQ_TRY(hipStreamWaitEvent(c->seq_compute, ev_down, 0));
         st = mpc_encode_tiles_device(c, d_rgb, width, height, static_cast<size_t>(3) * width, 0, tiles_y, quant, d_counts, d_choices,
@@ -858,8 +886,7 @@ mpc_status mpc_encode_images(mpc_context* c, const uint8_t* const* rgb_frames, i
         });
     }
 #undef MPC_SEQ_TRY
-    collect(pending[0]);
-    collect(pending[1]);
+    for (int f = n_frames; f < n_frames + static_cast<int>(S); ++f) collect(pending[f % static_cast<int>(S)]);   // oldest first
     (void)hipStreamSynchronize(c->seq_up);
     (void)hipStreamSynchronize(c->seq_compute);
     (void)hipStreamSynchronize(c->seq_down);
