@@ -86,6 +86,8 @@ def _bind_bitstream(L):
                                        C.POINTER(_u16p), C.POINTER(C.c_size_t), C.POINTER(_u8p), C.POINTER(C.c_size_t)]
     L.mpc_assemble_streams.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _dp, _u16p, vp,
                                        C.POINTER(_u8p), C.POINTER(C.c_size_t)]
+    L.mpc_assemble_planar_streams.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _dp, _u16p, vp,
+                                       C.POINTER(_u8p), C.POINTER(C.c_size_t)]
     L.mpc_read_compressed.argtypes = [_u8p, C.c_size_t, C.POINTER(vp)]
     L.mpc_streams_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.mpc_streams_quant.argtypes = [vp, _u16p]
@@ -187,6 +189,18 @@ def assemble_streams(width, height, K, block_size, quant, counts, choices):
     out, n = _u8p(), C.c_size_t(0)
     _check(L.mpc_assemble_streams(width, height, K, block_size, q.ctypes.data_as(_dp), cp, ch.ctypes.data_as(C.c_void_p),
                                   C.byref(out), C.byref(n)))
+    return _take_bytes(L, out, n)
+
+
+def assemble_planar_streams(width, height, K, block_size, quant, counts, planar):
+    """assemble_streams for records in planar order, planar[ch, step, tile] (uint32 deltaId | intCoeff << 16)."""
+    L = load_library()
+    q = np.ascontiguousarray(quant, np.float64).reshape(3 * K)
+    cn, cp = _u16(counts)
+    pl = np.ascontiguousarray(planar)
+    out, n = _u8p(), C.c_size_t(0)
+    _check(L.mpc_assemble_planar_streams(width, height, K, block_size, q.ctypes.data_as(_dp), cp, pl.ctypes.data_as(C.c_void_p),
+                                         C.byref(out), C.byref(n)))
     return _take_bytes(L, out, n)
 
 

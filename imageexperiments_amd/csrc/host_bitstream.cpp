@@ -759,8 +759,13 @@ std::vector<uint8_t> write_compressed(const Streams& s) {
 // freshly faulted pages at K = 32): one job per (channel, step) gathers its two streams into buffers the worker thread
 // keeps between calls and codes them straight into its part of the container.  Same bytes as the two-step route.
 namespace {
+// record (tile t, channel ch, step i) = choices[t * tile_stride + ch * channel_stride + i * step_stride]
+struct RecordLayout {
+    size_t tile_stride, channel_stride, step_stride;
+};
+
 void code_records(int width, int height, int K, int block_size, const double* quant, const uint16_t* counts, const uint32_t* choices,
-                  BitWriter& out, std::vector<BitWriter>& parts) {
+                  const RecordLayout& layout, BitWriter& out, std::vector<BitWriter>& parts) {
     const size_t tiles = static_cast<size_t>((width + block_size - 1) / block_size) *
                          static_cast<size_t>((height + block_size - 1) / block_size);
     out.put(kMagic, 32);
@@ -796,12 +801,13 @@ void code_records(int width, int height, int K, int block_size, const double* qu
         const int job = job0 - 1;
         const int i = job / 3, ch = job - 3 * i;                 // job order: (step 0: Y U V), (step 1: Y U V), ...
         thread_local std::vector<uint16_t> d, c, scratch;
+        const uint32_t* mine = choices + static_cast<size_t>(ch) * layout.channel_stride + static_cast<size_t>(i) * layout.step_stride;
+        const size_t tile_stride = layout.tile_stride;
         d.clear();
         c.clear();
         for (size_t t = 0; t < tiles; ++t) {
-            const size_t o = 3 * t + static_cast<size_t>(ch);
-            if (counts[o] > i) {
-                const uint32_t rec = choices[o * K + i];
+            if (counts[3 * t + static_cast<size_t>(ch)] > i) {
+                const uint32_t rec = mine[t * tile_stride];
                 d.push_back(static_cast<uint16_t>(rec & 0xFFFFu));
                 c.push_back(static_cast<uint16_t>(rec >> 16));
             }
@@ -865,7 +871,7 @@ std::vector<uint8_t> encode_records(int width, int height, int K, int block_size
                                     const uint32_t* choices) {
     BitWriter out;
     std::vector<BitWriter> parts;
-    code_records(width, height, K, block_size, quant, counts, choices, out, parts);
+    code_records(width, height, K, block_size, quant, counts, choices, RecordLayout{3 * static_cast<size_t>(K), static_cast<size_t>(K), 1}, out, parts);
     for (const BitWriter& w : parts) out.append(w);
     return out.bytes();
 }
@@ -874,7 +880,17 @@ uint8_t* encode_records_malloc(int width, int height, int K, int block_size, con
                                const uint32_t* choices, size_t* nbytes) {
     BitWriter head;
     std::vector<BitWriter> parts;
-    code_records(width, height, K, block_size, quant, counts, choices, head, parts);
+    code_records(width, height, K, block_size, quant, counts, choices, RecordLayout{3 * static_cast<size_t>(K), static_cast<size_t>(K), 1}, head, parts);
+    return concat_malloc(head, parts, nbytes);
+}
+
+uint8_t* encode_planar_records_malloc(int width, int height, int K, int block_size, const double* quant, const uint16_t* counts,
+                                      const uint32_t* planar, size_t* nbytes) {
+    const size_t tiles = static_cast<size_t>((width + block_size - 1) / block_size) *
+                         static_cast<size_t>((height + block_size - 1) / block_size);
+    BitWriter head;
+    std::vector<BitWriter> parts;
+    code_records(width, height, K, block_size, quant, counts, planar, RecordLayout{1, static_cast<size_t>(K) * tiles, tiles}, head, parts);
     return concat_malloc(head, parts, nbytes);
 }
 
@@ -972,10 +988,11 @@ Streams assemble_streams(int width, int height, int K, int block_size, const dou
         const int ch = job / K, i = job - ch * K;
         std::vector<uint16_t>& d = s.codes[2 * K * ch + 2 * i];
         std::vector<uint16_t>& c = s.codes[2 * K * ch + 2 * i + 1];
+        const uint32_t* mine = choices + static_cast<size_t>(ch) * K + static_cast<size_t>(i);
+        const size_t tile_stride = 3 * static_cast<size_t>(K);
         for (size_t t = 0; t < tiles; ++t) {
-            const size_t o = 3 * t + static_cast<size_t>(ch);
-            if (counts[o] > i) {
-                const uint32_t rec = choices[o * K + i];
+            if (counts[3 * t + static_cast<size_t>(ch)] > i) {
+                const uint32_t rec = mine[t * tile_stride];
                 d.push_back(static_cast<uint16_t>(rec & 0xFFFFu));
                 c.push_back(static_cast<uint16_t>(rec >> 16));
             }

@@ -81,6 +81,10 @@ std::vector<uint8_t> encode_records(int width, int height, int K, int block_size
 // the same into a malloc'ed buffer (release with free); nullptr = out of memory
 uint8_t* encode_records_malloc(int width, int height, int K, int block_size, const double* quant, const uint16_t* counts,
                                const uint32_t* choices, size_t* nbytes);
+// same container from records in planar order, planar[(ch * K + i) * tiles + t]: every (channel, step) job then reads
+// one contiguous run instead of one word per 12*K bytes (what mpc_encode_image downloads after the device transposes)
+uint8_t* encode_planar_records_malloc(int width, int height, int K, int block_size, const double* quant, const uint16_t* counts,
+                                      const uint32_t* planar, size_t* nbytes);
 
 // Inverse of assemble_streams: per-tile records in the reference's visiting order.  counts[3*tiles],
 // choices[3*tiles*K] (deltaId | intCoeff << 16, zero beyond count).  false = streams inconsistent with `lengths`.

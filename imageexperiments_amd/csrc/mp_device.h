@@ -131,6 +131,9 @@ struct DecodeParams {
 };
 int launch_decode(const DictDevice& dict, const DecodeParams& p, void* stream);
 
+// choices[tiles][3][K] -> planar[3][K][tiles] (what the host entropy stage of mpc_encode_image(s) reads); hipError_t as int
+int launch_planar_records(const uint32_t* choices, uint32_t* planar, long long tiles, int K, void* stream);
+
 // bytes of workspace needed for `cap` tile-channels and K steps
 size_t workspace_bytes(int cap, int K);
 // carve a workspace out of one device allocation of workspace_bytes(cap, K) bytes

@@ -1662,6 +1662,36 @@ int enqueue_pursuit(const DictDevice& dict, const Workspace& ws, const FrameInpu
     return (int)hipGetLastError();
 }
 
+// ---- records [tiles][3][K] -> planar [3][K][tiles] ----
+// For the host entropy stage of mpc_encode_image(s): every (channel, step) stream is then one contiguous run of the
+// download instead of one word per 12*K bytes.  64 tiles per block through LDS, both sides coalesced.
+__global__ void __launch_bounds__(256) mp_planar_records_kernel(const uint32_t* __restrict__ choices, uint32_t* __restrict__ planar,
+                                                                int tiles, int K) {
+    extern __shared__ uint32_t planar_lds[];            // [64][3K + 1]
+    const int rows = 3 * K, pitch = rows + 1;
+    const long long t0 = static_cast<long long>(blockIdx.x) * 64;
+    const int nt = static_cast<int>(min(64LL, static_cast<long long>(tiles) - t0));
+    const uint32_t* src = choices + t0 * rows;
+    for (int idx = threadIdx.x; idx < nt * rows; idx += 256) {
+        const int tt = idx / rows, r = idx - tt * rows;
+        planar_lds[tt * pitch + r] = src[idx];
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < rows * 64; idx += 256) {
+        const int r = idx >> 6, tt = idx & 63;
+        if (tt < nt) planar[static_cast<size_t>(r) * tiles + t0 + tt] = planar_lds[tt * pitch + r];
+    }
+}
+
+int launch_planar_records(const uint32_t* choices, uint32_t* planar, long long tiles, int K, void* stream) {
+    if (tiles <= 0) return 0;
+    const unsigned blocks = static_cast<unsigned>((tiles + 63) / 64);
+    const size_t lds = sizeof(uint32_t) * 64 * (3 * static_cast<size_t>(K) + 1);
+    hipLaunchKernelGGL(mp_planar_records_kernel, dim3(blocks), dim3(256), lds, static_cast<hipStream_t>(stream), choices, planar,
+                       static_cast<int>(tiles), K);
+    return static_cast<int>(hipGetLastError());
+}
+
 int launch_decode(const DictDevice& dict, const DecodeParams& p, void* stream)
 {
     const long long tiles = (long long)p.tiles_x * p.tiles_y;

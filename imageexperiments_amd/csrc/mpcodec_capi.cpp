@@ -416,9 +416,10 @@ mpc_status mpc_encode_tiles_device(mpc_context* c, const uint8_t* d_rgb, int wid
                                    d_counts, d_choices, d_energy, d_swept, waves, stream);
 }
 
-mpc_status mpc_encode_tiles(mpc_context* c, const uint8_t* rgb, int width, int height, size_t row_stride,
-                            int tile_row_begin, int tile_row_end, const double* quant, uint16_t* counts,
-                            mpc_basis_choice* choices, double* energy, uint32_t* swept) {
+// upload, pursuit, download through the context's staging area; planar = the records come back as [3][K][tiles]
+static mpc_status encode_tiles_staged(mpc_context* c, const uint8_t* rgb, int width, int height, size_t row_stride,
+                                      int tile_row_begin, int tile_row_end, const double* quant, uint16_t* counts,
+                                      mpc_basis_choice* choices, double* energy, uint32_t* swept, bool planar) {
     if (!c) return fail(MPC_ERR_ARGUMENT, "null context");
     if (c->device < 0) return fail(MPC_ERR_NO_DEVICE, "context was created without a device; there is no CPU fallback");
     if (!rgb || !counts || !choices) return fail(MPC_ERR_ARGUMENT, "null buffer");
@@ -431,7 +432,8 @@ mpc_status mpc_encode_tiles(mpc_context* c, const uint8_t* rgb, int width, int h
     const size_t n_tc = static_cast<size_t>(tiles) * 3;
     const size_t off_counts = up(img_bytes), off_choices = off_counts + up(sizeof(uint16_t) * n_tc),
                  off_energy = off_choices + up(sizeof(mpc_basis_choice) * n_tc * c->K), off_swept = off_energy + up(sizeof(double) * n_tc),
-                 total = off_swept + up(sizeof(uint32_t) * n_tc);
+                 off_planar = off_swept + up(sizeof(uint32_t) * n_tc),
+                 total = off_planar + (planar ? up(sizeof(mpc_basis_choice) * n_tc * c->K) : 0);
     if (total > c->stage_bytes) {
         if (c->stage) (void)hipFree(c->stage);
         c->stage = nullptr;
@@ -451,10 +453,17 @@ mpc_status mpc_encode_tiles(mpc_context* c, const uint8_t* rgb, int width, int h
     if (e == hipSuccess) {
         st = mpc_encode_tiles_device(c, d_rgb, width, height, row_stride, tile_row_begin, tile_row_end, quant, d_counts,
                                      d_choices, d_energy, d_swept, 0, nullptr);
+        const mpc_basis_choice* d_records = d_choices;
+        if (st == MPC_OK && planar) {
+            uint32_t* d_planar = reinterpret_cast<uint32_t*>(base + off_planar);
+            const int err = mpc::launch_planar_records(reinterpret_cast<const uint32_t*>(d_choices), d_planar, tiles, c->K, nullptr);
+            if (err != 0) st = fail(MPC_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(err)));
+            d_records = reinterpret_cast<const mpc_basis_choice*>(d_planar);
+        }
         if (st == MPC_OK) {
             e = hipDeviceSynchronize();
             if (e == hipSuccess) e = hipMemcpy(counts, d_counts, sizeof(uint16_t) * n_tc, hipMemcpyDeviceToHost);
-            if (e == hipSuccess) e = hipMemcpy(choices, d_choices, sizeof(mpc_basis_choice) * n_tc * c->K, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(choices, d_records, sizeof(mpc_basis_choice) * n_tc * c->K, hipMemcpyDeviceToHost);
             if (e == hipSuccess && energy) e = hipMemcpy(energy, d_energy, sizeof(double) * n_tc, hipMemcpyDeviceToHost);
             if (e == hipSuccess && swept) e = hipMemcpy(swept, d_swept, sizeof(uint32_t) * n_tc, hipMemcpyDeviceToHost);
         }
@@ -462,6 +471,13 @@ mpc_status mpc_encode_tiles(mpc_context* c, const uint8_t* rgb, int width, int h
     if (st != MPC_OK) return st;
     if (e != hipSuccess) return fail(MPC_ERR_HIP, "HIP failure: %s", hipGetErrorString(e));
     return MPC_OK;
+}
+
+mpc_status mpc_encode_tiles(mpc_context* c, const uint8_t* rgb, int width, int height, size_t row_stride,
+                            int tile_row_begin, int tile_row_end, const double* quant, uint16_t* counts,
+                            mpc_basis_choice* choices, double* energy, uint32_t* swept) {
+    return encode_tiles_staged(c, rgb, width, height, row_stride, tile_row_begin, tile_row_end, quant, counts, choices, energy, swept,
+                               false);
 }
 
 mpc_status mpc_histogram_device(mpc_context* c, const uint16_t* d_counts, const mpc_basis_choice* d_choices,
@@ -649,6 +665,14 @@ mpc_status mpc_assemble_streams(int width, int height, int K, int block_size, co
     return *bytes ? MPC_OK : fail(MPC_ERR_ALLOC, "out of memory");
 }
 
+mpc_status mpc_assemble_planar_streams(int width, int height, int K, int block_size, const double* quant,
+                                       const uint16_t* counts, const mpc_basis_choice* planar, uint8_t** bytes, size_t* nbytes) {
+    if (!quant || !counts || !planar || !bytes || !nbytes || K < 1 || K > MPC_MAX_K || block_size < 1 || width < 1 || height < 1)
+        return fail(MPC_ERR_ARGUMENT, "bad argument");
+    *bytes = mpc::encode_planar_records_malloc(width, height, K, block_size, quant, counts, reinterpret_cast<const uint32_t*>(planar), nbytes);
+    return *bytes ? MPC_OK : fail(MPC_ERR_ALLOC, "out of memory");
+}
+
 mpc_status mpc_read_compressed(const uint8_t* bytes, size_t nbytes, mpc_streams** out) {
     if (!bytes || !out) return fail(MPC_ERR_ARGUMENT, "null argument");
     mpc_streams* h = new (std::nothrow) mpc_streams;
@@ -746,10 +770,13 @@ mpc_status mpc_encode_image(mpc_context* c, const uint8_t* rgb, int width, int h
     }
     uint16_t* counts = static_cast<uint16_t*>(c->host_stage);
     mpc_basis_choice* choices = reinterpret_cast<mpc_basis_choice*>(static_cast<char*>(c->host_stage) + counts_bytes);
-    mpc_status st = mpc_encode_tiles(c, rgb, width, height, static_cast<size_t>(3) * width, 0, tiles_y, quant, counts, choices,
-                                     nullptr, nullptr);
+    // the records are transposed on the device ([3][K][tiles]) so that every stream of the container is one contiguous
+    // run of the download for the entropy stage
+    mpc_status st = encode_tiles_staged(c, rgb, width, height, static_cast<size_t>(3) * width, 0, tiles_y, quant, counts, choices,
+                                        nullptr, nullptr, true);
     if (st != MPC_OK) return st;
-    return mpc_assemble_streams(width, height, c->K, c->block_size, quant ? quant : c->quant.data(), counts, choices, bytes, nbytes);
+    return mpc_assemble_planar_streams(width, height, c->K, c->block_size, quant ? quant : c->quant.data(), counts, choices, bytes,
+                                       nbytes);
 }
 
 mpc_status mpc_encode_images(mpc_context* c, const uint8_t* const* rgb_frames, int n_frames, int width, int height,
@@ -773,7 +800,8 @@ mpc_status mpc_encode_images(mpc_context* c, const uint8_t* const* rgb_frames, i
     auto up = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
     const size_t img_bytes = static_cast<size_t>(3) * width * height;
     const size_t counts_bytes = up(sizeof(uint16_t) * n_tc), choices_bytes = up(sizeof(mpc_basis_choice) * n_tc * c->K);
-    const size_t dev_slot = up(img_bytes) + counts_bytes + choices_bytes, host_slot = dev_slot;   // image | counts | choices
+    const size_t host_slot = up(img_bytes) + counts_bytes + choices_bytes;    // image | counts | planar records
+    const size_t dev_slot = host_slot + choices_bytes;                        // image | counts | records | planar records
     constexpr size_t S = mpc_context::kSeqSlots;
     if (S * host_slot > c->host_stage_bytes) {
         if (c->host_stage) (void)hipHostFree(c->host_stage);
@@ -869,11 +897,14 @@ mpc_status mpc_encode_images(mpc_context* c, const uint8_t* const* rgb_frames, i
         st = mpc_encode_tiles_device(c, d_rgb, width, height, static_cast<size_t>(3) * width, 0, tiles_y, quant, d_counts, d_choices,
                                      nullptr, nullptr, 0, c->seq_compute);
         if (st != MPC_OK) break;
+        uint32_t* d_planar = reinterpret_cast<uint32_t*>(dbase + up(img_bytes) + counts_bytes + choices_bytes);
+        MPC_SEQ_TRY(static_cast<hipError_t>(mpc::launch_planar_records(reinterpret_cast<const uint32_t*>(d_choices), d_planar,
+                                                                     static_cast<long long>(tiles), c->K, c->seq_compute)));
         MPC_SEQ_TRY(hipEventRecord(ev_comp, c->seq_compute));
         // download into the pinned slot
         MPC_SEQ_TRY(hipStreamWaitEvent(c->seq_down, ev_comp, 0));
         MPC_SEQ_TRY(hipMemcpyAsync(counts, d_counts, sizeof(uint16_t) * n_tc, hipMemcpyDeviceToHost, c->seq_down));
-        MPC_SEQ_TRY(hipMemcpyAsync(choices, d_choices, sizeof(mpc_basis_choice) * n_tc * c->K, hipMemcpyDeviceToHost, c->seq_down));
+        MPC_SEQ_TRY(hipMemcpyAsync(choices, d_planar, sizeof(mpc_basis_choice) * n_tc * c->K, hipMemcpyDeviceToHost, c->seq_down));
         MPC_SEQ_TRY(hipEventRecord(ev_down, c->seq_down));
         used[sl] = true;
         const int K = c->K, bs = c->block_size, device = c->device;
@@ -881,7 +912,7 @@ mpc_status mpc_encode_images(mpc_context* c, const uint8_t* const* rgb_frames, i
         slot.result = std::async(std::launch::async, [=]() -> std::pair<uint8_t*, size_t> {
             if (hipSetDevice(device) != hipSuccess || hipEventSynchronize(ev_down) != hipSuccess) return {nullptr, 0};
             size_t n = 0;
-            uint8_t* blob = mpc::encode_records_malloc(width, height, K, bs, q, counts, reinterpret_cast<const uint32_t*>(choices), &n);
+            uint8_t* blob = mpc::encode_planar_records_malloc(width, height, K, bs, q, counts, reinterpret_cast<const uint32_t*>(choices), &n);
             return {blob, n};
         });
     }

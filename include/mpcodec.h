@@ -166,6 +166,11 @@ mpc_status mpc_write_compressed(int width, int height, int K, int block_size, co
 mpc_status mpc_assemble_streams(int width, int height, int K, int block_size, const double* quant,
                                 const uint16_t* counts, const mpc_basis_choice* choices, uint8_t** bytes, size_t* nbytes);
 
+/* Same container from records in planar order, planar[(channel * K + step) * tiles + t] (what mpc_encode_image
+ * downloads after transposing on the device: each stream's records are then one contiguous run for the host). */
+mpc_status mpc_assemble_planar_streams(int width, int height, int K, int block_size, const double* quant,
+                                       const uint16_t* counts, const mpc_basis_choice* planar, uint8_t** bytes, size_t* nbytes);
+
 /* readCompressed (CompressedImage.cpp:635): parse a container; streams come back with the DC differencing
  * undone.  index -1 = lengths, 0..6K-1 = codes[index]. */
 mpc_status mpc_read_compressed(const uint8_t* bytes, size_t nbytes, mpc_streams** out);

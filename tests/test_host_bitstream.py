@@ -191,3 +191,6 @@ def test_records_to_container_equals_oracle(ia, oracle, monkeypatch, size, K, bp
     choices = delta.astype(np.uint32) | (coef.astype(np.uint32) << 16)
     blob = ia.assemble_streams(w, h, K, 8, octx.quant, counts, choices)
     assert bytes(blob) == bytes(octx.encode_image(rgb))
+    # the planar record order mpc_encode_image downloads ([3][K][tiles]) gives the same container
+    planar = np.ascontiguousarray(choices.reshape(-1, 3, K).transpose(1, 2, 0))
+    assert bytes(ia.api.assemble_planar_streams(w, h, K, 8, octx.quant, counts, planar)) == bytes(blob)
