@@ -436,3 +436,32 @@ def test_launch_configurations_do_not_change_records(gpu, oracle, monkeypatch, e
     octx = oracle.OracleContext(16, 8, 3.0)
     _compare(ctx.encode_tiles(rgb), octx.encode_tiles(rgb), 16)
     ctx.close()
+
+
+@pytest.mark.parametrize("K", [1, 8, 32])
+def test_degenerate_frames_bytes_equal_oracle(gpu, oracle, K):
+    """Flat frames (black: every residual is zero from the start; white and grey: only the DC atom matters), one-pixel
+    checkerboards and stripes (energy in the highest frequencies), hard 0/255 noise and a 1x1 image, for the smallest
+    and the largest K: container bytes equal the oracle's and decode to the oracle's pixels."""
+    import imageexperiments_amd as ia
+    ctx = ia.create_compression_context(K, 8, 3.5, device=0)
+    octx = oracle.OracleContext(K, 8, 3.5)
+    H, W = 24, 40
+    yy, xx = np.mgrid[0:H, 0:W]
+    rng = np.random.default_rng(K)
+    frames = {
+        "black": np.zeros((H, W, 3), np.uint8),
+        "white": np.full((H, W, 3), 255, np.uint8),
+        "grey": np.full((H, W, 3), 128, np.uint8),
+        "checker": np.repeat((((xx + yy) & 1) * 255).astype(np.uint8)[:, :, None], 3, axis=2),
+        "stripes": np.stack([((xx & 1) * 255), ((yy & 1) * 255), (((xx >> 2) & 1) * 255)], axis=2).astype(np.uint8),
+        "hard noise": (rng.integers(0, 2, (H, W, 3)) * 255).astype(np.uint8),
+        "one pixel": np.array([[[200, 30, 90]]], np.uint8),
+        "one column": rng.integers(0, 256, (19, 1, 3)).astype(np.uint8),
+    }
+    for name, rgb in frames.items():
+        rgb = np.ascontiguousarray(rgb)
+        blob, ref = ctx.encode_image(rgb), octx.encode_image(rgb)
+        assert blob == ref, name
+        assert (ia.decode_image(blob, ctx) == oracle.decode_image(ref)).all(), name
+    ctx.close()
