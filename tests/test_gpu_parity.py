@@ -412,6 +412,10 @@ def test_pipelined_frames_equal_single_frame_calls(gpu, oracle):
     assert batch == singles
     octx = oracle.OracleContext(8, 8, 3.5)
     assert batch[3] == bytes(octx.encode_image(frames[3]))
+    # more frames than slots, then a larger and a smaller geometry on the same context (staging regrows), then one frame
+    for (w, h, n) in ((320, 200, 11), (500, 333, 6), (64, 40, 9), (64, 40, 1)):
+        frames = [oracle.synth_frame(w, h, 900 + 7 * f) for f in range(n)]
+        assert [bytes(b) for b in ctx.encode_images(frames)] == [bytes(ctx.encode_image(f)) for f in frames], (w, h, n)
     ctx.close()
 
 
