@@ -469,3 +469,38 @@ def test_degenerate_frames_bytes_equal_oracle(gpu, oracle, K):
         assert blob == ref, name
         assert (ia.decode_image(blob, ctx) == oracle.decode_image(ref)).all(), name
     ctx.close()
+
+
+@pytest.mark.parametrize("world,rank", [(2, 0), (2, 1), (4, 2), (8, 7)])
+def test_batch_stripe_launch_equals_oracle(gpu, oracle, world, rank):
+    """What one rank does per step in `bench.py --gpus N`: stripe `rank` of `world` frames in ONE launch of
+    mpc_encode_batch_device, output tile index = frame * tiles_per_stripe + tx * rows + (ty - row_begin).  Checked
+    against the oracle's whole-frame records of every frame, restricted to the stripe."""
+    import imageexperiments_amd as ia
+    from imageexperiments_amd.sharding import stripe_bounds
+    torch = gpu
+    K, W, H = 8, 136, 100                                    # 17 x 13 tiles, ragged in both directions
+    tiles_x, tiles_y = (W + 7) // 8, (H + 7) // 8
+    r0, r1 = stripe_bounds(tiles_y, world, rank)
+    rows = r1 - r0
+    frames = world
+    ctx = ia.create_compression_context(K, 8, 3.5, device=0)
+    octx = oracle.OracleContext(K, 8, 3.5)
+    host = np.stack([oracle.synth_frame(W, H, 40 + f) for f in range(frames)])
+    d_rgb = torch.from_numpy(host).cuda()
+    tiles = frames * tiles_x * rows
+    d_counts = torch.zeros((max(tiles, 1), 3), dtype=torch.int16, device="cuda")
+    d_choices = torch.zeros((max(tiles, 1), 3, K), dtype=torch.int32, device="cuda")
+    if rows > 0:
+        ctx.encode_batch_device(d_rgb.data_ptr(), frames, W * H * 3, W, H, W * 3, r0, r1, d_counts.data_ptr(), d_choices.data_ptr())
+        torch.cuda.synchronize()
+    counts = d_counts.cpu().numpy().view(np.uint16)[:tiles].reshape(frames, tiles_x, rows, 3)
+    choices = d_choices.cpu().numpy().view(np.uint32)[:tiles].reshape(frames, tiles_x, rows, 3, K)
+    for f in range(frames):
+        oc, od, ok, _, _ = octx.encode_tiles(host[f])
+        oc = oc.reshape(tiles_x, tiles_y, 3)[:, r0:r1]
+        orec = (od.astype(np.uint32) | (ok.astype(np.uint32) << 16)).reshape(tiles_x, tiles_y, 3, K)[:, r0:r1]
+        assert (counts[f] == oc).all(), f
+        live = np.arange(K)[None, None, None, :] < np.minimum(oc.astype(np.int64) + 1, K)[..., None]   # records 0..count
+        assert (choices[f][live] == orec[live]).all(), f
+    ctx.close()
