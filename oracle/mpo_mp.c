@@ -335,19 +335,21 @@ struct mpo_patch_stats {
     mpo_stat s[3][2][MPO_MAX_K];      /* [channel][0 = intCoeff, 1 = deltaId][step] */
 };
 
-static void stat_update(mpo_stat *s, double val)                   /* covariance.cpp:5-21 */
+static void stat_update(mpo_stat *s, double val)                   /* covariance.cpp:5-21 (Welford) */
 {
-    if (s->N == 0) {
-        s->N = 1.0; s->min = val; s->max = val; s->mean = val; s->sumSq = 0.0;
-    } else {
-        if (val < s->min) s->min = val;
-        if (val > s->max) s->max = val;
-        s->N += 1.0;
-        double delta = val - s->mean;
-        s->mean += delta / s->N;
-        double delta2 = val - s->mean;
-        s->sumSq += delta * delta2;
+    if (s->N == 0) {                       /* first sample defines min, max and mean */
+        s->N = 1.0;
+        s->min = s->max = s->mean = val;
+        s->sumSq = 0.0;
+        return;
     }
+    if (val < s->min) s->min = val;
+    if (val > s->max) s->max = val;
+    s->N += 1.0;
+    const double before = val - s->mean;   /* distance to the old mean ... */
+    s->mean += before / s->N;
+    const double after = val - s->mean;    /* ... and to the new one */
+    s->sumSq += before * after;
 }
 
 mpo_patch_stats *mpo_patch_stats_create(int K, uint32_t seed)      /* Compression.cpp:210-220 */
