@@ -1229,7 +1229,6 @@ __global__ __launch_bounds__(256) void mp_finish_kernel(const Workspace ws, cons
     const unsigned swept = ws.swept[tc] + (unsigned)(dict.num_base + extra);
     ws.swept[tc] = swept;
 
-    const double* r = ws.r + (long long)tc * N;
     bool done = false;
     int count = 0;
     unsigned record = 0;
@@ -1267,19 +1266,8 @@ __global__ __launch_bounds__(256) void mp_finish_kernel(const Workspace ws, cons
     ws.upd_coeff[tc] = coeff;
     ws.upd_sel[tc] = best_sel;
     if (done) {
-        // energy of the final residual, sequential like the oracle; when this step still subtracts an atom
-        // (count == K) the subtraction is folded in with the same two roundings as the update kernel
-        const double* row = (best_sel < 0) ? (dict.base + (long long)(~best_sel) * N)
-                                           : (dict.detail + ((long long)ch * dict.detail_rows + best_sel) * N);
-        double e2 = 0.0;
-        if (out.energy) {
-            for (int j = 0; j < N; ++j) {
-                double v = r[j];
-                if (coeff != 0.0) { const double scaled = coeff * row[j]; v = v - scaled; }
-                e2 += v * v;
-            }
-            out.energy[rec] = e2;
-        }
+        // the energy of the final residual (diagnostic output) is summed by mp_energy_kernel after the last step: the
+        // residual row of a finished tile-channel does not change any more and its last update stays in upd_coeff/upd_sel
         out.counts[rec] = (uint16_t)count;
         if (out.swept) out.swept[rec] = swept;
     } else {
@@ -1576,6 +1564,52 @@ FilterArgs filter_args(const Workspace& ws, const DictDevice& dict, int cur)
 }
 }  // namespace
 
+// Final residual energies (Outputs::energy, a diagnostic the reference does not compute), once per batch after the last
+// step.  A wave takes 64 tile-channels: lane = pixel for coalesced reads of the residual rows, eight rows in flight (and
+// the atom of a still pending update, count == K, folded in with the update's two roundings); the squares go through LDS
+// so that lane k adds tile-channel k's 64 terms in the oracle's order.
+__global__ __launch_bounds__(64) void mp_energy_kernel(const Workspace ws, const DictDevice dict, const Outputs out, int n)
+{
+    __shared__ double sq[64 * 65];
+    const int lane = (int)threadIdx.x;
+    for (long long first = (long long)blockIdx.x * 64; first < n; first += (long long)gridDim.x * 64) {
+        const int here = (int)(n - first < 64 ? n - first : 64);
+        const long long mine = first + (lane < here ? lane : 0);
+        const double my_coeff = ws.upd_coeff[mine];
+        const int my_sel = ws.upd_sel[mine];
+        const unsigned my_out = (unsigned)ws.out_index[mine];
+        for (int i0 = 0; i0 < here; i0 += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u < here ? i0 + u : here - 1;
+                v[u] = ws.r[(first + i) * N + lane];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u < here ? i0 + u : here - 1;
+                const double coeff = __shfl(my_coeff, i);
+                if (coeff != 0.0) {
+                    const int sel = __shfl(my_sel, i);
+                    const int ch = (int)((unsigned)__shfl((int)my_out, i) >> 30);
+                    const double* row = (sel < 0) ? (dict.base + (long long)(~sel) * N)
+                                                  : (dict.detail + ((long long)ch * dict.detail_rows + sel) * N);
+                    const double scaled = coeff * row[lane];
+                    v[u] = v[u] - scaled;
+                }
+                sq[i * 65 + lane] = v[u] * v[u];
+            }
+        }
+        __syncthreads();
+        if (lane < here) {
+            double e2 = 0.0;
+            for (int j = 0; j < N; ++j) e2 += sq[lane * 65 + j];
+            out.energy[(long long)(my_out & 0x3FFFFFFFu)] = e2;
+        }
+        __syncthreads();
+    }
+}
+
 int enqueue_pursuit(const DictDevice& dict, const Workspace& ws, const FrameInput& in, const Outputs& out,
                     const double* quant_dev, int K, long long tc_begin, int n, int parts, int row_parts, int sweep_waves,
                     void* stream_, void** base_events, void* side_stream_, void* fork_event_, void* join_event_)
@@ -1659,6 +1693,7 @@ int enqueue_pursuit(const DictDevice& dict, const Workspace& ws, const FrameInpu
             }
         }
     }
+    if (out.energy) hipLaunchKernelGGL(mp_energy_kernel, dim3(clampu((unsigned)((n + 63) / 64), 4096u)), dim3(64), 0, s, ws, dict, out, n);
     return (int)hipGetLastError();
 }
 
