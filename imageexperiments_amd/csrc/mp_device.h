@@ -13,6 +13,7 @@
 //     detail   (s>0) every other unlocked detail block, bucketed by (channel, block)
 //     finish   argmax in dictionary order, quantise, record, unlock block, compact  (MatchingPursuit.cpp:55-71)
 //     update   residual update                                                      (mathvector.cpp:116-148)
+//   after the last step, if asked for: energy  sum of squares of every final residual (diagnostic)
 // filter/detail find the maximum without correlating every row in double: bf16 matrix-core approximations with a
 // proven error bound select the one or two rows per tile-channel that can win, and only those are evaluated in the
 // reference's sequential double arithmetic (mp_kernels.hip).  The exhaustive double sweeps remain as a cross-check.

@@ -1565,15 +1565,16 @@ FilterArgs filter_args(const Workspace& ws, const DictDevice& dict, int cur)
 }  // namespace
 
 // Final residual energies (Outputs::energy, a diagnostic the reference does not compute), once per batch after the last
-// step.  A wave takes 64 tile-channels: lane = pixel for coalesced reads of the residual rows, eight rows in flight (and
+// step.  A wave takes 16 tile-channels: lane = pixel for coalesced reads of the residual rows, eight rows in flight (and
 // the atom of a still pending update, count == K, folded in with the update's two roundings); the squares go through LDS
 // so that lane k adds tile-channel k's 64 terms in the oracle's order.
+constexpr int kEnergyGroup = 16;
 __global__ __launch_bounds__(64) void mp_energy_kernel(const Workspace ws, const DictDevice dict, const Outputs out, int n)
 {
-    __shared__ double sq[64 * 65];
+    __shared__ double sq[kEnergyGroup * 65];
     const int lane = (int)threadIdx.x;
-    for (long long first = (long long)blockIdx.x * 64; first < n; first += (long long)gridDim.x * 64) {
-        const int here = (int)(n - first < 64 ? n - first : 64);
+    for (long long first = (long long)blockIdx.x * kEnergyGroup; first < n; first += (long long)gridDim.x * kEnergyGroup) {
+        const int here = (int)(n - first < kEnergyGroup ? n - first : kEnergyGroup);
         const long long mine = first + (lane < here ? lane : 0);
         const double my_coeff = ws.upd_coeff[mine];
         const int my_sel = ws.upd_sel[mine];
@@ -1693,7 +1694,8 @@ int enqueue_pursuit(const DictDevice& dict, const Workspace& ws, const FrameInpu
             }
         }
     }
-    if (out.energy) hipLaunchKernelGGL(mp_energy_kernel, dim3(clampu((unsigned)((n + 63) / 64), 4096u)), dim3(64), 0, s, ws, dict, out, n);
+    if (out.energy)
+        hipLaunchKernelGGL(mp_energy_kernel, dim3(clampu((unsigned)((n + kEnergyGroup - 1) / kEnergyGroup), 8192u)), dim3(64), 0, s, ws, dict, out, n);
     return (int)hipGetLastError();
 }
 
