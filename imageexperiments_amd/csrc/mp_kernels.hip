@@ -636,10 +636,10 @@ __device__ __forceinline__ void drain_survivors(CandLds& lds, int lane, Survivor
         int n = __popcll(votes);
         if (n > kCandRound) n = kCandRound;
         unsigned long long left = votes;
-        for (int k0 = 0; k0 < n; k0 += 4) {                     // four survivors' reads in flight; slots past n repeat the last
-            double x[4], y[4];
+        for (int k0 = 0; k0 < n; k0 += 8) {                     // eight survivors' reads in flight; slots past n repeat the last
+            double x[8], y[8];
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
+            for (int kk = 0; kk < 8; ++kk) {
                 const int src = __builtin_ctzll(left);         // wave-uniform: the lane that put up survivor k0 + kk
                 if (left & (left - 1)) left &= left - 1;
                 const unsigned rl = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)row_addr, src);
@@ -650,7 +650,7 @@ __device__ __forceinline__ void drain_survivors(CandLds& lds, int lane, Survivor
                 y[kk] = ((const double*)(uintptr_t)(((unsigned long long)sh << 32) | sl))[lane];
             }
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) lds.prod[(k0 + kk) * kStageStride + lane] = x[kk] * y[kk];
+            for (int kk = 0; kk < 8; ++kk) lds.prod[(k0 + kk) * kStageStride + lane] = x[kk] * y[kk];
         }
         wave_lds_sync();
         if (lane < n) {
