@@ -443,12 +443,18 @@ void huffman_encode_with(const SymbolStats& st, const uint16_t* data, size_t n, 
 bool huffman_decode(BitReader& in, std::vector<uint16_t>& out) {
     const int max_length = static_cast<int>(in.get(8));
     std::vector<uint16_t> counts(static_cast<size_t>(max_length));
-    uint16_t total = 0;
+    size_t entries = 0;
     for (int l = 0; l < max_length; ++l) {
         counts[l] = static_cast<uint16_t>(in.get(16));
-        total = static_cast<uint16_t>(total + counts[l]);
+        entries += counts[l];
     }
+    // the reference keeps this sum in a uint16_t (Huffman.cpp:176): a table of more than 65535 entries wraps there and
+    // cannot come from its encoder; a symbol width above 16 overflows its mask.  Both are invalid data here.
+    if (entries > 65535) return false;
+    const uint16_t total = static_cast<uint16_t>(entries);
     const int symbol_bits = static_cast<int>(in.get(8));
+    if (symbol_bits < 1 || symbol_bits > 16) return false;
+    if (entries > in.remaining()) return false;                 // every table entry takes at least one bit
     const uint16_t mask = static_cast<uint16_t>((1u << symbol_bits) - 1u);
     std::vector<uint16_t> table(total);
     size_t at = 0;
@@ -575,6 +581,29 @@ std::vector<uint16_t> rle_decode(const uint16_t* data, size_t n) {
     return out;
 }
 
+// size rle_decode would produce, or false once it exceeds `limit`
+bool rle_decoded_size(const uint16_t* data, size_t n, size_t limit, size_t* size) {
+    size_t total = 0;
+    uint16_t prev = 0;
+    bool expect_count = false, fresh = true;
+    for (size_t i = 0; i < n; ++i) {
+        const uint16_t v = data[i];
+        if (expect_count) {
+            total += v;
+            expect_count = false;
+            fresh = true;
+        } else {
+            ++total;
+            if (v == prev && !fresh) expect_count = true;
+            fresh = false;
+            prev = v;
+        }
+        if (total > limit) return false;
+    }
+    *size = total;
+    return true;
+}
+
 // CompressedImage.cpp:359-401.  The Golomb cost of each candidate M is the sum over DISTINCT symbols of
 // count x length -- same number as the reference's per-symbol loop.
 void write_huffman_or_golomb(const uint16_t* data, size_t n, BitWriter& out) {
@@ -602,6 +631,7 @@ bool read_huffman_or_golomb(BitReader& in, size_t length, std::vector<uint16_t>&
     if (in.get(1) == 0) return huffman_decode(in, out);
     const uint32_t m = static_cast<uint32_t>(in.get(16));
     if (m == 0) return false;
+    if (length > in.remaining()) return false;                  // every Golomb code takes at least one bit: a lying header
     out.reserve(out.size() + length);
     for (size_t i = 0; i < length; ++i) out.push_back(static_cast<uint16_t>(golomb_read(m, in)));
     return true;
@@ -909,7 +939,11 @@ bool read_compressed(const uint8_t* bytes, size_t nbytes, Streams& s) {
     const size_t tiles = static_cast<size_t>((s.width + s.block_size - 1) / s.block_size) *
                          static_cast<size_t>((s.height + s.block_size - 1) / s.block_size);
     s.lengths.clear();
+    if (tiles > (static_cast<size_t>(1) << 40) / 3) return false;
     if (!read_huffman_or_golomb(in, 3 * tiles, s.lengths)) return false;
+    // a Huffman-coded lengths stream carries its own end: it must still describe exactly this frame's tiles (the
+    // device decoder walks tiles_x * tiles_y records)
+    if (s.lengths.size() != 3 * tiles) return false;
     s.codes.assign(static_cast<size_t>(6 * K), {});
     // length of an un-packed stream = tile-channels of its layer with more than `depth` atoms (:680-685): suffix sums
     // of the histogram of lengths, once for all 6K streams
@@ -928,15 +962,19 @@ bool read_compressed(const uint8_t* bytes, size_t nbytes, Streams& s) {
         }
     }
     for (int i = 0; i < 6 * K; ++i) {
+        const size_t expect = expect_of[(static_cast<size_t>(i / 2) / K) * static_cast<size_t>(K) + static_cast<size_t>(i / 2) % K];
         if (in.get(1) == 1) {
             const size_t packed_len = static_cast<size_t>(in.get(32));
             std::vector<uint16_t> packed;
             if (!read_huffman_or_golomb(in, packed_len, packed)) return false;
+            // run lengths come from the data: refuse to expand beyond what the lengths stream allows for this stream
+            size_t expanded = 0;
+            if (!rle_decoded_size(packed.data(), packed.size(), expect, &expanded)) return false;
             s.codes[i] = rle_decode(packed.data(), packed.size());
         } else {
-            const size_t layer = static_cast<size_t>(i / 2) / K, depth = static_cast<size_t>(i / 2) % K;
-            if (!read_huffman_or_golomb(in, expect_of[layer * static_cast<size_t>(K) + depth], s.codes[i])) return false;
+            if (!read_huffman_or_golomb(in, expect, s.codes[i])) return false;
         }
+        if (s.codes[i].size() != expect) return false;
     }
     for (int idx : {1, 2 * K + 1, 4 * K + 1}) {                  // :690-705
         int32_t acc = 0;

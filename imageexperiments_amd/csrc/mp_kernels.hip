@@ -851,6 +851,10 @@ __global__ __launch_bounds__(64, MPC_WAVE_OCC) void mp_filter_wave_kernel(const 
 
         // ---- pass 2, only for column groups with an unclear tile-channel: the same MFMAs again; rows at or above the
         //      threshold queue up for exact evaluation
+        // pass 2 pushes up to four rows of a lane per tile before it looks at the fill level: enter it with room for them
+        if ((second_pass[0] || second_pass[1] || second_pass[2] || second_pass[3]) &&
+            __ballot(queue.count > SurvivorQueue::kCapacity - 4))
+            drain_survivors(s_cand, lane, queue, fa.base, block0, res0, res1, res2, res3, best);
         if (second_pass[0] || second_pass[1] || second_pass[2] || second_pass[3])
             for_each_tile<DEPTH>(0, ntiles, tile_ptr, [&](int tile, const uint4 (&a)[4]) {
                 const bool is_base = tile < kBaseFilterTiles;

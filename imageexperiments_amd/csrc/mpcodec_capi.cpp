@@ -14,6 +14,8 @@
 #include <utility>
 #include <stdexcept>
 #include <future>
+#include <memory>
+#include <mutex>
 #include <vector>
 
 #include "host_bitstream.h"
@@ -40,6 +42,22 @@ mpc_status fail(mpc_status st, const char* fmt, ...) {
         if (e_ != hipSuccess) return fail(MPC_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
     } while (0)
 
+// No exception crosses the C ABI (the reference throws heap-allocated std::range_error*; here: status codes)
+template <class F>
+mpc_status guarded(F&& body) {
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        return fail(MPC_ERR_ALLOC, "out of memory");
+    } catch (const std::length_error& e) {
+        return fail(MPC_ERR_ALLOC, "allocation size out of range: %s", e.what());
+    } catch (const std::exception& e) {
+        return fail(MPC_ERR_BITSTREAM, "%s", e.what());
+    } catch (...) {
+        return fail(MPC_ERR_BITSTREAM, "unknown failure");
+    }
+}
+
 template <class T>
 hipError_t upload(T** dst, const T* src, size_t count) {
     hipError_t e = hipMalloc(reinterpret_cast<void**>(dst), count * sizeof(T));
@@ -57,7 +75,13 @@ struct mpc_context {
     // device residents (uploaded once)
     double* d_base = nullptr;
     double* d_detail = nullptr;
-    double* d_quant = nullptr;
+    double* d_quant = nullptr;        // the context's tables; only mpc_context_set_quant changes them
+    // per-call quantiser overrides (the `quant` argument of the encode / decode entry points) go to a ring of device
+    // slots of their own, so that a later call with quant == NULL still quantises with the context's tables
+    static constexpr int kQuantSlots = 16;
+    double* d_quant_ring = nullptr;   // [kQuantSlots][3 * MPC_MAX_K]
+    unsigned quant_next = 0;
+    std::recursive_mutex host_calls;  // the host-buffer entry points share the staging buffers below
     int32_t* d_rows = nullptr;
     int32_t* d_rowoff = nullptr;
     uint16_t* d_base_f32 = nullptr;   // filter copies (mp_device.h)
@@ -111,6 +135,16 @@ int env_int(const char* name, int fallback) {
 long long max_batch() {
     const int tiles = env_int("MPC_MAX_BATCH_TILES", 0);
     return tiles > 0 ? 3LL * ((tiles + 255) / 256 * 256) : kMaxBatchDefault;
+}
+
+// device table a call quantises with: the context's, or a ring slot holding the call's override (copied on `s`)
+mpc_status call_quant(mpc_context* c, const double* quant, hipStream_t s, const double** d_q) {
+    *d_q = c->d_quant;
+    if (!quant) return MPC_OK;
+    double* slot = c->d_quant_ring + static_cast<size_t>(c->quant_next++ % mpc_context::kQuantSlots) * 3 * MPC_MAX_K;
+    HIP_TRY(hipMemcpyAsync(slot, quant, 3 * sizeof(double) * c->K, hipMemcpyHostToDevice, s));
+    *d_q = slot;
+    return MPC_OK;
 }
 
 mpc::DictDevice dict_device(const mpc_context* c) {
@@ -232,6 +266,7 @@ const char* mpc_version(void) { return "mpcodec 0.1 (gfx950)"; }
 const char* mpc_last_error(void) { return g_error; }
 
 mpc_status mpc_context_create(int K, int block_size, double bpp, int device, mpc_context** out) {
+    return guarded([&]() -> mpc_status {
     if (!out) return fail(MPC_ERR_ARGUMENT, "out is null");
     *out = nullptr;
     if (K < 1 || K > MPC_MAX_K) return fail(MPC_ERR_ARGUMENT, "K=%d out of range 1..%d", K, MPC_MAX_K);
@@ -269,6 +304,8 @@ mpc_status mpc_context_create(int K, int block_size, double bpp, int device, mpc
         if (e == hipSuccess) e = upload(&c->d_base, base.data(), base.size());
         if (e == hipSuccess) e = upload(&c->d_detail, det.data(), det.size());
         if (e == hipSuccess) e = upload(&c->d_quant, c->quant.data(), c->quant.size());
+        if (e == hipSuccess)
+            e = hipMalloc(reinterpret_cast<void**>(&c->d_quant_ring), sizeof(double) * mpc_context::kQuantSlots * 3 * MPC_MAX_K);
         if (e == hipSuccess) e = upload(&c->d_rows, c->dict.block_rows.data(), c->dict.block_rows.size());
         if (e == hipSuccess) e = upload(&c->d_rowoff, c->dict.block_row_off.data(), c->dict.block_row_off.size());
         // split-bfloat16 copies for the filter pass: base rows as 32 tiles of 16 rows, every detail block as 4
@@ -296,6 +333,7 @@ mpc_status mpc_context_create(int K, int block_size, double bpp, int device, mpc
     }
     *out = c;
     return MPC_OK;
+    });
 }
 
 void mpc_context_destroy(mpc_context* c) {
@@ -305,6 +343,7 @@ void mpc_context_destroy(mpc_context* c) {
         (void)hipFree(c->d_base);
         (void)hipFree(c->d_detail);
         (void)hipFree(c->d_quant);
+        (void)hipFree(c->d_quant_ring);
         (void)hipFree(c->d_rows);
         (void)hipFree(c->d_rowoff);
         (void)hipFree(c->d_base_f32);
@@ -385,7 +424,8 @@ mpc_status mpc_encode_batch_device(mpc_context* c, const uint8_t* d_rgb, int fra
     if (tiles * 3 >= (1LL << 31)) return fail(MPC_ERR_ARGUMENT, "batch too large");
     hipStream_t s = static_cast<hipStream_t>(stream);
     HIP_TRY(hipSetDevice(c->device));
-    if (quant) HIP_TRY(hipMemcpyAsync(c->d_quant, quant, 3 * sizeof(double) * c->K, hipMemcpyHostToDevice, s));
+    const double* d_q = nullptr;
+    if (const mpc_status qs = call_quant(c, quant, s, &d_q); qs != MPC_OK) return qs;
     HIP_TRY(hipMemsetAsync(d_choices, 0, sizeof(mpc_basis_choice) * tiles * 3 * c->K, s));
     mpc::FrameInput in{};
     in.rgb = d_rgb;
@@ -405,7 +445,7 @@ mpc_status mpc_encode_batch_device(mpc_context* c, const uint8_t* d_rgb, int fra
     out.energy = d_energy;
     out.swept = d_swept;
     (void)waves;
-    return run_pursuit(c, in, out, c->d_quant, tiles * 3, stream);
+    return run_pursuit(c, in, out, d_q, tiles * 3, stream);
 }
 
 mpc_status mpc_encode_tiles_device(mpc_context* c, const uint8_t* d_rgb, int width, int height, size_t row_stride,
@@ -423,6 +463,7 @@ static mpc_status encode_tiles_staged(mpc_context* c, const uint8_t* rgb, int wi
     if (!c) return fail(MPC_ERR_ARGUMENT, "null context");
     if (c->device < 0) return fail(MPC_ERR_NO_DEVICE, "context was created without a device; there is no CPU fallback");
     if (!rgb || !counts || !choices) return fail(MPC_ERR_ARGUMENT, "null buffer");
+    std::lock_guard<std::recursive_mutex> one_host_call(c->host_calls);
     HIP_TRY(hipSetDevice(c->device));
     const int tiles_x = (width + 7) / 8;
     const long long tiles = static_cast<long long>(tiles_x) * (tile_row_end - tile_row_begin);
@@ -644,6 +685,7 @@ void mpc_free(void* p) { std::free(p); }
 mpc_status mpc_write_compressed(int width, int height, int K, int block_size, const double* quant,
                                 const uint16_t* lengths, size_t n_lengths, const uint16_t* const* codes,
                                 const size_t* code_lengths, uint8_t** bytes, size_t* nbytes) {
+    return guarded([&]() -> mpc_status {
     if (!quant || !bytes || !nbytes || (!lengths && n_lengths) || !codes || !code_lengths || K < 1 || K > MPC_MAX_K)
         return fail(MPC_ERR_ARGUMENT, "bad argument");
     mpc::Streams s;
@@ -655,34 +697,37 @@ mpc_status mpc_write_compressed(int width, int height, int K, int block_size, co
     for (int i = 0; i < 6 * K; ++i) s.codes[i].assign(codes[i], codes[i] + code_lengths[i]);
     *bytes = give_bytes(mpc::write_compressed(s), nbytes);
     return *bytes ? MPC_OK : fail(MPC_ERR_ALLOC, "out of memory");
+    });
 }
 
 mpc_status mpc_assemble_streams(int width, int height, int K, int block_size, const double* quant,
                                 const uint16_t* counts, const mpc_basis_choice* choices, uint8_t** bytes, size_t* nbytes) {
+    return guarded([&]() -> mpc_status {
     if (!quant || !counts || !choices || !bytes || !nbytes || K < 1 || K > MPC_MAX_K || block_size < 1 || width < 1 || height < 1)
         return fail(MPC_ERR_ARGUMENT, "bad argument");
     *bytes = mpc::encode_records_malloc(width, height, K, block_size, quant, counts, reinterpret_cast<const uint32_t*>(choices), nbytes);
     return *bytes ? MPC_OK : fail(MPC_ERR_ALLOC, "out of memory");
+    });
 }
 
 mpc_status mpc_assemble_planar_streams(int width, int height, int K, int block_size, const double* quant,
                                        const uint16_t* counts, const mpc_basis_choice* planar, uint8_t** bytes, size_t* nbytes) {
+    return guarded([&]() -> mpc_status {
     if (!quant || !counts || !planar || !bytes || !nbytes || K < 1 || K > MPC_MAX_K || block_size < 1 || width < 1 || height < 1)
         return fail(MPC_ERR_ARGUMENT, "bad argument");
     *bytes = mpc::encode_planar_records_malloc(width, height, K, block_size, quant, counts, reinterpret_cast<const uint32_t*>(planar), nbytes);
     return *bytes ? MPC_OK : fail(MPC_ERR_ALLOC, "out of memory");
+    });
 }
 
 mpc_status mpc_read_compressed(const uint8_t* bytes, size_t nbytes, mpc_streams** out) {
+    return guarded([&]() -> mpc_status {
     if (!bytes || !out) return fail(MPC_ERR_ARGUMENT, "null argument");
-    mpc_streams* h = new (std::nothrow) mpc_streams;
-    if (!h) return fail(MPC_ERR_ALLOC, "out of memory");
-    if (!mpc::read_compressed(bytes, nbytes, h->s)) {
-        delete h;
-        return fail(MPC_ERR_BITSTREAM, "Invalid input data");
-    }
-    *out = h;
+    std::unique_ptr<mpc_streams> h(new mpc_streams);
+    if (!mpc::read_compressed(bytes, nbytes, h->s)) return fail(MPC_ERR_BITSTREAM, "Invalid input data");
+    *out = h.release();
     return MPC_OK;
+    });
 }
 
 mpc_status mpc_streams_info(const mpc_streams* h, int* width, int* height, int* K, int* block_size) {
@@ -720,41 +765,51 @@ mpc_status mpc_streams_copy(const mpc_streams* h, int index, uint16_t* dst) {
 void mpc_streams_free(mpc_streams* h) { delete h; }
 
 mpc_status mpc_huffman_encode(const uint16_t* data, size_t n, uint8_t** bytes, size_t* nbytes) {
+    return guarded([&]() -> mpc_status {
     if ((!data && n) || !bytes || !nbytes) return fail(MPC_ERR_ARGUMENT, "null argument");
     mpc::BitWriter w;
     mpc::huffman_encode(data, n, w);
     *bytes = give_bytes(w.bytes(), nbytes);
     return *bytes ? MPC_OK : fail(MPC_ERR_ALLOC, "out of memory");
+    });
 }
 
 mpc_status mpc_huffman_decode(const uint8_t* bytes, size_t nbytes, uint16_t** data, size_t* n) {
+    return guarded([&]() -> mpc_status {
     if (!bytes || !data || !n) return fail(MPC_ERR_ARGUMENT, "null argument");
     mpc::BitReader r(bytes, nbytes);
     std::vector<uint16_t> out;
     if (!mpc::huffman_decode(r, out)) return fail(MPC_ERR_BITSTREAM, "Invalid bitstream");
     *data = give_u16(out, n);
     return *data ? MPC_OK : fail(MPC_ERR_ALLOC, "out of memory");
+    });
 }
 
 mpc_status mpc_rle_encode(const uint16_t* data, size_t n, uint16_t** out, size_t* n_out) {
+    return guarded([&]() -> mpc_status {
     if ((!data && n) || !out || !n_out) return fail(MPC_ERR_ARGUMENT, "null argument");
     *out = give_u16(mpc::rle_encode(data, n), n_out);
     return *out ? MPC_OK : fail(MPC_ERR_ALLOC, "out of memory");
+    });
 }
 
 mpc_status mpc_rle_decode(const uint16_t* data, size_t n, uint16_t** out, size_t* n_out) {
+    return guarded([&]() -> mpc_status {
     if ((!data && n) || !out || !n_out) return fail(MPC_ERR_ARGUMENT, "null argument");
     *out = give_u16(mpc::rle_decode(data, n), n_out);
     return *out ? MPC_OK : fail(MPC_ERR_ALLOC, "out of memory");
+    });
 }
 
 // compressed::encodeImage: device tile encode + host entropy stage
 mpc_status mpc_encode_image(mpc_context* c, const uint8_t* rgb, int width, int height, const double* quant,
                             uint8_t** bytes, size_t* nbytes) {
+    return guarded([&]() -> mpc_status {
     if (!c || !rgb || !bytes || !nbytes) return fail(MPC_ERR_ARGUMENT, "null argument");
     if (c->device < 0) return fail(MPC_ERR_NO_DEVICE, "context was created without a device; there is no CPU fallback");
     const int tiles_x = (width + 7) / 8, tiles_y = (height + 7) / 8;
     const size_t tiles = static_cast<size_t>(tiles_x) * tiles_y;
+    std::lock_guard<std::recursive_mutex> one_host_call(c->host_calls);
     // the records come back into pinned host memory kept by the context (a fresh 100 MB vector per call costs more in
     // page faults than the device spends encoding)
     HIP_TRY(hipSetDevice(c->device));
@@ -777,10 +832,12 @@ mpc_status mpc_encode_image(mpc_context* c, const uint8_t* rgb, int width, int h
     if (st != MPC_OK) return st;
     return mpc_assemble_planar_streams(width, height, c->K, c->block_size, quant ? quant : c->quant.data(), counts, choices, bytes,
                                        nbytes);
+    });
 }
 
 mpc_status mpc_encode_images(mpc_context* c, const uint8_t* const* rgb_frames, int n_frames, int width, int height,
                              const double* quant, uint8_t** bytes, size_t* nbytes) {
+    return guarded([&]() -> mpc_status {
     if (!c || !rgb_frames || !bytes || !nbytes || n_frames < 1) return fail(MPC_ERR_ARGUMENT, "bad argument");
     if (c->device < 0) return fail(MPC_ERR_NO_DEVICE, "context was created without a device; there is no CPU fallback");
     if (width < 1 || height < 1) return fail(MPC_ERR_ARGUMENT, "bad geometry");
@@ -792,6 +849,7 @@ mpc_status mpc_encode_images(mpc_context* c, const uint8_t* const* rgb_frames, i
     const int tiles_y = (height + 7) / 8;
     const size_t tiles = static_cast<size_t>((width + 7) / 8) * tiles_y;
     const size_t n_tc = tiles * 3;
+    std::lock_guard<std::recursive_mutex> one_host_call(c->host_calls);
     HIP_TRY(hipSetDevice(c->device));
     // Three stages over kSeqSlots slots: while the device encodes frame f (compute stream), frame f+1 is uploaded
     // (upload stream, via the slot's pinned image), the records of frame f-1 travel
@@ -925,6 +983,7 @@ mpc_status mpc_encode_images(mpc_context* c, const uint8_t* const* rgb_frames, i
         for (int f = 0; f < n_frames; ++f) { std::free(bytes[f]); bytes[f] = nullptr; nbytes[f] = 0; }
     }
     return st;
+    });
 }
 
 // FromCoeffsDynamic + RGBFromYUV for whole tiles on the device; d_quant: [3][K] doubles on the device
@@ -955,20 +1014,22 @@ mpc_status mpc_decode_tiles_device(mpc_context* c, const uint16_t* d_counts, con
     if (c->device < 0) return fail(MPC_ERR_NO_DEVICE, "context was created without a device");
     if (width < 1 || height < 1) return fail(MPC_ERR_ARGUMENT, "bad geometry");
     HIP_TRY(hipSetDevice(c->device));
-    if (quant)
-        HIP_TRY(hipMemcpyAsync(c->d_quant, quant, 3 * sizeof(double) * c->K, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)));
-    return decode_tiles_on_device(c, d_counts, reinterpret_cast<const uint32_t*>(d_choices), c->d_quant, c->K, width, height, d_rgb,
+    const double* d_q = nullptr;
+    if (const mpc_status qs = call_quant(c, quant, static_cast<hipStream_t>(stream), &d_q); qs != MPC_OK) return qs;
+    return decode_tiles_on_device(c, d_counts, reinterpret_cast<const uint32_t*>(d_choices), d_q, c->K, width, height, d_rgb,
                                   stream);
 }
 
 // compressed::decodeImage: container parsing on the host, tile reconstruction on the device.  The stream's own
 // K and quantisation table are used (they need not match the context's); there is no host reconstruction.
 mpc_status mpc_decode_image(const mpc_context* cc, const uint8_t* bytes, size_t nbytes, uint8_t** rgb, int* width, int* height) {
+    return guarded([&]() -> mpc_status {
     if (!cc || !bytes || !rgb || !width || !height) return fail(MPC_ERR_ARGUMENT, "null argument");
     mpc_context* c = const_cast<mpc_context*>(cc);
     if (c->device < 0) return fail(MPC_ERR_NO_DEVICE, "context was created without a device; there is no CPU fallback");
     mpc::Streams s;
     if (!mpc::read_compressed(bytes, nbytes, s)) return fail(MPC_ERR_BITSTREAM, "Invalid input data");
+    std::lock_guard<std::recursive_mutex> one_host_call(c->host_calls);     // concurrent decodes share the staging buffers
     if (s.block_size != c->block_size) return fail(MPC_ERR_ARGUMENT, "stream block size %d, context block size %d", s.block_size, c->block_size);
     // records via the context's pinned host buffer and device staging area (grow-only, shared with the encoder)
     HIP_TRY(hipSetDevice(c->device));
@@ -1021,6 +1082,7 @@ mpc_status mpc_decode_image(const mpc_context* cc, const uint8_t* bytes, size_t 
     *width = s.width;
     *height = s.height;
     return MPC_OK;
+    });
 }
 
 // ---- "-s" patch statistics (Compression.cpp:200-302) ----
@@ -1045,6 +1107,7 @@ mpc_status mpc_patch_stats_create(mpc_context* c, unsigned seed, mpc_patch_stats
 void mpc_patch_stats_destroy(mpc_patch_stats* s) { delete s; }
 
 mpc_status mpc_patch_stats_add_image(mpc_patch_stats* s, const uint8_t* rgb, int width, int height, int patches) {
+    return guarded([&]() -> mpc_status {
     if (!s || !rgb) return fail(MPC_ERR_ARGUMENT, "null argument");
     const int bs = s->stats.block_size, K = s->stats.K;
     if (width < bs || height < bs || patches <= 0) return MPC_OK;            // Compression.cpp:233-236
@@ -1066,6 +1129,7 @@ mpc_status mpc_patch_stats_add_image(mpc_patch_stats* s, const uint8_t* rgb, int
     if (st != MPC_OK) return st;
     s->stats.accumulate(s->counts.data(), s->choices.data(), patches);
     return MPC_OK;
+    });
 }
 
 mpc_status mpc_patch_stats_read(const mpc_patch_stats* s, double* out) {
@@ -1082,6 +1146,7 @@ mpc_status mpc_patch_stats_read(const mpc_patch_stats* s, double* out) {
 }
 
 mpc_status mpc_patch_stats_report(const mpc_patch_stats* s, char** text, size_t* nbytes) {
+    return guarded([&]() -> mpc_status {
     if (!s || !text || !nbytes) return fail(MPC_ERR_ARGUMENT, "null argument");
     const std::string r = s->stats.report();
     char* p = static_cast<char*>(std::malloc(r.size() + 1));
@@ -1090,6 +1155,7 @@ mpc_status mpc_patch_stats_report(const mpc_patch_stats* s, char** text, size_t*
     *text = p;
     *nbytes = r.size();
     return MPC_OK;
+    });
 }
 
 int mpc_format_double(double v, char* buf, int cap) {

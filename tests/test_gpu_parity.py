@@ -504,3 +504,73 @@ def test_batch_stripe_launch_equals_oracle(gpu, oracle, world, rank):
         live = np.arange(K)[None, None, None, :] < np.minimum(oc.astype(np.int64) + 1, K)[..., None]   # records 0..count
         assert (choices[f][live] == orec[live]).all(), f
     ctx.close()
+
+
+def test_nan_vectors_end_the_pursuit_like_the_reference(ctx32, octx32):
+    """A NaN anywhere in the input makes every projection NaN; `abs(p) > best` is false for all rows, Select returns -1
+    and CalcMPDynamic returns 0 (MatchingPursuit.cpp:50-54).  The filter must not lose that: NaN approximations keep
+    every row as a survivor and the exact evaluations decide.  (Infinities are left out: round(inf / q) -> int is
+    undefined behaviour in the reference.)"""
+    rng = np.random.default_rng(77)
+    v = rng.integers(0, 256, (12, 64)).astype(np.float64)
+    v[0, :] = np.nan
+    v[1, 0] = np.nan
+    v[2, 63] = np.nan
+    v[3, 17] = -np.nan
+    v[4, ::2] = np.nan
+    for channel in (0, 1):
+        counts, choices, energy, swept = ctx32.calc_mp(channel, v)
+        for i in range(v.shape[0]):
+            cnt, d, k, res, S = octx32.calc_mp(channel, v[i])
+            assert counts[i] == cnt, i
+            n = min(cnt + 1, 32) if i >= 5 else 0
+            assert (choices["deltaId"][i, :n] == d[:n]).all(), i
+            assert (choices["intCoeff"][i, :n] == k[:n]).all(), i
+            assert swept[i] == S, i
+        assert (counts[:5] == 0).all()
+
+
+def test_many_near_ties_on_one_lane(ctx32, octx32):
+    """ADVICE r1 (survivor queue): residuals built as equal-weight sums of several base rows give a tile-channel three or
+    more rows inside the filter window at once, next to clear neighbours in the same column group."""
+    base, rows, det = ctx32.dictionary()
+    rng = np.random.default_rng(123)
+    v = []
+    for rep in range(48):
+        r0 = int(rng.integers(1, 500))
+        picks = [r0, r0 + 1, r0 + 2, r0 + 3, r0 + 4][: 3 + rep % 3]         # adjacent rows: the four rows of one lane
+        w = sum(base[p] for p in picks) * 300.0
+        v.append(w)
+        v.append(rng.integers(0, 256, 64).astype(np.float64))               # a clear neighbour
+    v = np.array(v)
+    counts, choices, energy, swept = ctx32.calc_mp(0, v)
+    for i in range(v.shape[0]):
+        cnt, d, k, res, S = octx32.calc_mp(0, v[i])
+        assert counts[i] == cnt, i
+        n = min(cnt + 1, 32)
+        assert (choices["deltaId"][i, :n] == d[:n]).all(), i
+        assert (choices["intCoeff"][i, :n] == k[:n]).all(), i
+        assert swept[i] == S, i
+
+
+def test_quant_override_does_not_stick(ctx32, octx32, oracle):
+    """a per-call quantiser table must not replace the context's device table.  Encode with an
+    override (explicitly, and through the patch statistics, which quantise with all ones), then with quant=None:
+    the container must be the oracle's for the context's own tables."""
+    import imageexperiments_amd as ia
+    rgb = oracle.synth_frame(104, 72, 31)
+    want = bytes(octx32.encode_image(rgb))
+    assert bytes(ctx32.encode_image(rgb)) == want
+    ones = np.ones((3, 32))
+    ctx32.encode_tiles(rgb, quant=ones)
+    assert bytes(ctx32.encode_image(rgb)) == want
+    ps = ia.api.PatchStatistics(ctx32, 7)
+    ps.add_image(rgb, 32)
+    ps.close()
+    assert bytes(ctx32.encode_image(rgb)) == want
+    custom = octx32.quant * 2.0
+    assert bytes(ctx32.encode_image(rgb, quant=custom)) == bytes(octx32.encode_image(rgb, quant=custom))
+    assert bytes(ctx32.encode_image(rgb)) == want
+    # decode side: an override on mpc_decode_tiles_device must not stick either
+    back = ia.api.decode_image(want, ctx32)
+    assert (back == oracle.decode_image(want)).all()

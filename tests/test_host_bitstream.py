@@ -194,3 +194,50 @@ def test_records_to_container_equals_oracle(ia, oracle, monkeypatch, size, K, bp
     # the planar record order mpc_encode_image downloads ([3][K][tiles]) gives the same container
     planar = np.ascontiguousarray(choices.reshape(-1, 3, K).transpose(1, 2, 0))
     assert bytes(ia.api.assemble_planar_streams(w, h, K, 8, octx.quant, counts, planar)) == bytes(blob)
+
+
+def _small_container(oracle, W=40, H=24, K=4):
+    rng = np.random.default_rng(11)
+    rgb = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    return oracle.OracleContext(K, 8, 3.5).encode_image(rgb)
+
+
+def test_truncated_and_corrupted_containers_are_errors_not_crashes(ia, oracle, mn_bytes):
+    """the parser must not trust the header.  Every prefix / bit flip either parses to streams that are
+    consistent with the header (lengths == 3 * tiles, every stream its expected length) or returns
+    MPC_ERR_BITSTREAM / MPC_ERR_ALLOC -- no exception may cross the C ABI and nothing may be sized from a lying field."""
+    blob = _small_container(oracle)
+    st = ia.read_compressed(blob)
+    tiles = ((st["W"] + 7) // 8) * ((st["H"] + 7) // 8)
+    assert len(st["lengths"]) == 3 * tiles
+    bad = 0
+    for cut in list(range(0, 64)) + list(range(64, len(blob), 7)):
+        try:
+            s = ia.read_compressed(blob[:cut])
+        except ia.MpcError as e:
+            assert e.status in (ia.api.MPC_ERR_BITSTREAM, ia.api.MPC_ERR_ALLOC)
+            bad += 1
+            continue
+        t = ((s["W"] + 7) // 8) * ((s["H"] + 7) // 8)
+        assert len(s["lengths"]) == 3 * t
+    assert bad > 0
+    rng = np.random.default_rng(3)
+    for _ in range(400):
+        b = bytearray(blob)
+        for _k in range(int(rng.integers(1, 4))):
+            b[int(rng.integers(0, len(b)))] ^= 1 << int(rng.integers(0, 8))
+        try:
+            s = ia.read_compressed(bytes(b))
+        except ia.MpcError as e:
+            assert e.status in (ia.api.MPC_ERR_BITSTREAM, ia.api.MPC_ERR_ALLOC)
+            continue
+        t = ((s["W"] + 7) // 8) * ((s["H"] + 7) // 8)
+        assert len(s["lengths"]) == 3 * t
+    # a header that claims a gigantic frame over a few bytes of data
+    huge = bytearray(mn_bytes[:4096])
+    huge[4:8] = (0x7FFFFFF0).to_bytes(4, "big")
+    huge[8:12] = (0x7FFFFFF0).to_bytes(4, "big")
+    with pytest.raises(ia.MpcError):
+        ia.read_compressed(bytes(huge))
+    with pytest.raises(ia.MpcError):
+        ia.read_compressed(mn_bytes[: len(mn_bytes) // 2])
