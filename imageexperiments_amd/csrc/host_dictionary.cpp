@@ -513,7 +513,7 @@ uint16_t bf16_round(float x) {
     return static_cast<uint16_t>(bits >> 16);
 }
 
-std::vector<uint16_t> filter_tiles(const double* rows, int nrows, int tiles) {
+std::vector<uint16_t> filter_tiles(const double* rows, int nrows, int tiles, int k_order, std::vector<uint8_t>* shadow_out) {
     std::vector<char> shadowed(static_cast<size_t>(nrows), 0);
     for (int j = 1; j < nrows; ++j)
         for (int i = 0; i < j && !shadowed[j]; ++i) {
@@ -526,13 +526,14 @@ std::vector<uint16_t> filter_tiles(const double* rows, int nrows, int tiles) {
             }
             if (same || negated) shadowed[j] = 1;
         }
+    if (shadow_out) shadow_out->assign(shadowed.begin(), shadowed.end());
     std::vector<uint16_t> out(static_cast<size_t>(tiles) * kFilterTileHalves, 0);
     for (int tile = 0; tile < tiles; ++tile)
         for (int kk = 0; kk < 2; ++kk)
             for (int lane = 0; lane < 64; ++lane)
                 for (int j = 0; j < 8; ++j) {
                     const int row = tile * 16 + (lane & 15);
-                    const int k = 32 * kk + 8 * (lane >> 4) + j;
+                    const int k = k_order == 0 ? 32 * kk + 8 * (lane >> 4) + j : 16 * (lane >> 4) + 8 * kk + j;
                     if (row >= nrows || shadowed[row]) continue;
                     const float x = static_cast<float>(rows[static_cast<size_t>(row) * kTileN + k]);
                     const uint16_t hi = bf16_round(x);

@@ -132,6 +132,46 @@ struct DecodeParams {
 };
 int launch_decode(const DictDevice& dict, const DecodeParams& p, void* stream);
 
+// ---- persistent pursuit (mp_pursuit.hip): one launch per channel runs all K steps of every tile-channel of that channel ----
+constexpr int kMaxPairs = 32;           // (tile-channel, unlocked block other than DetailBasis[0]) pairs a tile-channel can hold (< K)
+
+struct PursuitArgs {
+    // dictionary of this channel
+    const double* base;              // [512][64]
+    const double* detail;            // this channel's [detail_rows][64]
+    const uint16_t* base_tiles;      // [kBaseFilterTiles][2048], k order 1 (host_dictionary.h: filter_tiles)
+    const uint16_t* block_tiles;     // this channel's [num_base][kBlockFilterTiles][2048], k order 1
+    const float* gram;               // this channel's [num_base + detail_rows][gram_stride]
+    long long gram_stride;           // num_base * 64
+    const int32_t* block_rows;
+    const int32_t* block_row_off;
+    const double* quant;             // this channel's [K] (device)
+    int K, channel, num_base, rows0;
+    // input: tile mode (rgb) or vector mode (vec_in != nullptr: CalcMPDynamic on caller vectors of this channel)
+    const uint8_t* rgb;
+    int width, height;
+    long long row_stride, frame_stride;
+    int tile_row_begin, tile_rows, tiles_x;
+    const double* vec_in;
+    long long n_tc;                  // tile-channels of this channel (tiles of the stripe x frames, or vectors)
+    int n_units;                     // ceil(n_tc / 16)
+    unsigned* queue;                 // next unit (zero before the launch)
+    // per-wave scratch for the pairs (sizes: pursuit_scratch_*)
+    float* pair_p;
+    unsigned* pair_meta;
+    float* pair_e;
+    Outputs out;
+};
+
+int launch_pursuit(const PursuitArgs& args, int workgroups, void* stream);
+size_t pursuit_scratch_floats(int workgroups);
+size_t pursuit_scratch_meta(int workgroups);
+size_t pursuit_scratch_bounds(int workgroups);
+int pursuit_units_per_workgroup();
+// Gram table of one channel (see mp_pursuit.hip); shadow[detail_rows]: 1 = row left out of the filter copy
+int launch_gram(const double* base, const double* detail, const int32_t* block_rows, const int32_t* block_row_off,
+                const uint8_t* shadow, float* gram, int num_base, int n_sel, long long stride, void* stream);
+
 // choices[tiles][3][K] -> planar[3][K][tiles] (what the host entropy stage of mpc_encode_image(s) reads); hipError_t as int
 int launch_planar_records(const uint32_t* choices, uint32_t* planar, long long tiles, int K, void* stream);
 

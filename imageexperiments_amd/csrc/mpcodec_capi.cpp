@@ -67,11 +67,126 @@ hipError_t upload(T** dst, const T* src, size_t count) {
 
 }  // namespace
 
+// Everything on the device that depends only on (device, block size): the dictionary in double, its filter copies, the
+// Gram table and the persistent kernel's scratch, streams and queues.  Shared by every context of the process on that
+// device (a context adds K and the quantisation tables): the Gram table alone is 12.6 GB.  All persistent-kernel launches
+// of the process go through the three per-channel streams held here, which also serialises their use of the scratch.
+struct DeviceDict {
+    int device = -1;
+    int base_rows_padded = 0, num_base = 0, num_cus = 0;
+    long long detail_rows = 0;
+    double* d_base = nullptr;
+    double* d_detail = nullptr;
+    int32_t* d_rows = nullptr;
+    int32_t* d_rowoff = nullptr;
+    uint16_t* d_base_f32 = nullptr;   // filter copies, k order 0 (step-synchronous kernels)
+    uint16_t* d_detail_f32 = nullptr;
+    uint16_t* d_base_t1 = nullptr;    // filter copies, k order 1 (persistent kernel)
+    uint16_t* d_detail_t1 = nullptr;
+    uint8_t* d_shadow = nullptr;      // [3][detail_rows]
+    float* d_gram = nullptr;          // [3][num_base + detail_rows][num_base * 64]
+    std::mutex launch_lock;           // one enqueue sequence at a time
+    hipStream_t chan[3] = {};
+    hipEvent_t fork = nullptr, done[3] = {};
+    int workgroups = 0;               // scratch is sized for this many workgroups per launch
+    float* pair_p[3] = {};
+    unsigned* pair_meta[3] = {};
+    float* pair_e[3] = {};
+    unsigned* queues = nullptr;       // [3]
+    ~DeviceDict() {
+        if (device < 0) return;
+        (void)hipSetDevice(device);
+        (void)hipDeviceSynchronize();
+        (void)hipFree(d_base); (void)hipFree(d_detail); (void)hipFree(d_rows); (void)hipFree(d_rowoff);
+        (void)hipFree(d_base_f32); (void)hipFree(d_detail_f32); (void)hipFree(d_base_t1); (void)hipFree(d_detail_t1);
+        (void)hipFree(d_shadow); (void)hipFree(d_gram); (void)hipFree(queues);
+        for (int ch = 0; ch < 3; ++ch) {
+            (void)hipFree(pair_p[ch]); (void)hipFree(pair_meta[ch]); (void)hipFree(pair_e[ch]);
+            if (chan[ch]) (void)hipStreamDestroy(chan[ch]);
+            if (done[ch]) (void)hipEventDestroy(done[ch]);
+        }
+        if (fork) (void)hipEventDestroy(fork);
+    }
+};
+
+namespace {
+std::mutex g_dicts_lock;
+std::weak_ptr<DeviceDict> g_dicts[64];
+
+// build (or share) the device residents of `dict` on `device`
+hipError_t acquire_device_dict(int device, const mpc::Dictionary& dict, std::shared_ptr<DeviceDict>* out) {
+    std::lock_guard<std::mutex> hold(g_dicts_lock);
+    if (device < 64)
+        if (std::shared_ptr<DeviceDict> have = g_dicts[device].lock()) { *out = have; return hipSuccess; }
+    std::shared_ptr<DeviceDict> d = std::make_shared<DeviceDict>();
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return e;
+    d->device = device;
+    d->num_base = dict.num_base;
+    d->detail_rows = dict.total_detail_rows();
+    std::vector<double> base = mpc::base_padded(dict, 2, &d->base_rows_padded);
+    const size_t det_rows = static_cast<size_t>(dict.total_detail_rows());
+    // one zero row after the last: the exhaustive sweep's scalar prefetch reads one row past the rows it correlates
+    std::vector<double> det((3 * det_rows + 1) * mpc::kTileN, 0.0);
+    for (int ch = 0; ch < 3; ++ch)
+        std::memcpy(det.data() + ch * det_rows * mpc::kTileN, dict.detail[ch].data(), det_rows * mpc::kTileN * sizeof(double));
+    e = upload(&d->d_base, base.data(), base.size());
+    if (e == hipSuccess) e = upload(&d->d_detail, det.data(), det.size());
+    if (e == hipSuccess) e = upload(&d->d_rows, dict.block_rows.data(), dict.block_rows.size());
+    if (e == hipSuccess) e = upload(&d->d_rowoff, dict.block_row_off.data(), dict.block_row_off.size());
+    // split-bfloat16 filter copies: base rows as 32 tiles of 16 rows, every detail block as 4; both k orders
+    std::vector<uint8_t> shadow(3 * det_rows, 0);
+    for (int order = 0; order < 2 && e == hipSuccess; ++order) {
+        const std::vector<uint16_t> base32 = mpc::filter_tiles(dict.base.data(), dict.num_base, mpc::kBaseFilterTiles, order);
+        std::vector<uint16_t> det32;
+        det32.reserve(3 * static_cast<size_t>(dict.num_base) * mpc::kBlockFilterTiles * mpc::kFilterTileHalves);
+        for (int ch = 0; ch < 3; ++ch)
+            for (int b = 0; b < dict.num_base; ++b) {
+                std::vector<uint8_t> sh;
+                const std::vector<uint16_t> t = mpc::filter_tiles(
+                    dict.detail[ch].data() + static_cast<size_t>(dict.block_row_off[b]) * mpc::kTileN, dict.block_rows[b],
+                    mpc::kBlockFilterTiles, order, &sh);
+                det32.insert(det32.end(), t.begin(), t.end());
+                std::copy(sh.begin(), sh.end(), shadow.begin() + static_cast<size_t>(ch) * det_rows + static_cast<size_t>(dict.block_row_off[b]));
+            }
+        e = upload(order == 0 ? &d->d_base_f32 : &d->d_base_t1, base32.data(), base32.size());
+        if (e == hipSuccess) e = upload(order == 0 ? &d->d_detail_f32 : &d->d_detail_t1, det32.data(), det32.size());
+    }
+    if (e == hipSuccess) e = upload(&d->d_shadow, shadow.data(), shadow.size());
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&d->num_cus, hipDeviceAttributeMultiprocessorCount, device);
+    // Gram table, built on the device
+    const long long n_sel = dict.num_base + static_cast<long long>(det_rows), stride = static_cast<long long>(dict.num_base) * 64;
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d->d_gram), sizeof(float) * 3 * n_sel * stride);
+    for (int ch = 0; ch < 3 && e == hipSuccess; ++ch)
+        e = static_cast<hipError_t>(mpc::launch_gram(d->d_base, d->d_detail + static_cast<size_t>(ch) * det_rows * mpc::kTileN, d->d_rows,
+                                                     d->d_rowoff, d->d_shadow + static_cast<size_t>(ch) * det_rows,
+                                                     d->d_gram + static_cast<size_t>(ch) * n_sel * stride, dict.num_base,
+                                                     static_cast<int>(n_sel), stride, nullptr));
+    // persistent kernel: streams, events, queue words, per-wave scratch for one workgroup per CU
+    d->workgroups = d->num_cus > 0 ? d->num_cus : 1;
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&d->fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d->queues), 64);
+    for (int ch = 0; ch < 3 && e == hipSuccess; ++ch) {
+        e = hipStreamCreateWithFlags(&d->chan[ch], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&d->done[ch], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d->pair_p[ch]), sizeof(float) * mpc::pursuit_scratch_floats(d->workgroups));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d->pair_meta[ch]), sizeof(unsigned) * mpc::pursuit_scratch_meta(d->workgroups));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d->pair_e[ch]), sizeof(float) * mpc::pursuit_scratch_bounds(d->workgroups));
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) return e;
+    if (device < 64) g_dicts[device] = d;
+    *out = d;
+    return hipSuccess;
+}
+}  // namespace
+
 struct mpc_context {
     int K = 0, block_size = 0, device = -1;
     double bpp = 0.0;
     mpc::Dictionary dict;
     std::vector<double> quant;        // [3*K]
+    std::shared_ptr<DeviceDict> dd;   // owns the dictionary's device residents; the pointers below alias it
     // device residents (uploaded once)
     double* d_base = nullptr;
     double* d_detail = nullptr;
@@ -175,7 +290,14 @@ int pipes_for(const mpc_context* c, long long tile_channels) {
     return pipes;
 }
 
+// the step-synchronous kernels run only on request (MPC_PATH=steps, or MPC_FILTER=0 for their exhaustive sweeps)
+bool steps_path() {
+    const char* v = std::getenv("MPC_PATH");
+    return (v && std::strcmp(v, "steps") == 0) || env_int("MPC_FILTER", 1) == 0;
+}
+
 mpc_status ensure_workspace(mpc_context* c, long long tile_channels) {
+    if (!steps_path()) return MPC_OK;                 // the persistent kernel's scratch lives in the shared DeviceDict
     const int want_pipes = pipes_for(c, tile_channels);
     const long long kMaxBatch = max_batch();
     long long total = tile_channels < kMaxBatch ? tile_channels : kMaxBatch;
@@ -214,8 +336,85 @@ mpc_status ensure_workspace(mpc_context* c, long long tile_channels) {
 constexpr int kBaseParts = 8;
 constexpr int kRowParts = 4;
 
+
+// The persistent path (mp_pursuit.hip): one launch per channel on the device's three channel streams, forked from and joined
+// to the caller's stream with events.  No host synchronisation, no allocation.
+mpc_status run_persistent(mpc_context* c, const mpc::FrameInput& in, const mpc::Outputs& out, const double* d_quant,
+                          long long total_tc, void* stream) {
+    DeviceDict& d = *c->dd;
+    hipStream_t caller = static_cast<hipStream_t>(stream);
+    const bool vec = in.vec_in != nullptr;
+    const long long n_tc = vec ? total_tc : total_tc / 3;
+    const long long n_units = (n_tc + 15) / 16;
+    if (n_units >= (1LL << 31)) return fail(MPC_ERR_ARGUMENT, "batch too large");
+    const int per_wg = mpc::pursuit_units_per_workgroup();
+    int workgroups = static_cast<int>(std::min<long long>((n_units + per_wg - 1) / per_wg, d.workgroups));
+    const int forced = env_int("MPC_WORKGROUPS", 0);
+    if (forced > 0) workgroups = std::min(forced, d.workgroups);
+    std::lock_guard<std::mutex> hold(d.launch_lock);
+    HIP_TRY(hipEventRecord(d.fork, caller));
+    const long long n_sel = d.num_base + d.detail_rows, stride = static_cast<long long>(d.num_base) * 64;
+    for (int ch = 0; ch < 3; ++ch) {
+        if (vec && ch != in.vec_channel) continue;
+        hipStream_t s = d.chan[ch];
+        HIP_TRY(hipStreamWaitEvent(s, d.fork, 0));
+        HIP_TRY(hipMemsetAsync(d.queues + ch, 0, sizeof(unsigned), s));
+        mpc::PursuitArgs a{};
+        a.base = d.d_base;
+        a.detail = d.d_detail + static_cast<size_t>(ch) * d.detail_rows * mpc::kTileN;
+        a.base_tiles = d.d_base_t1;
+        a.block_tiles = d.d_detail_t1 + static_cast<size_t>(ch) * d.num_base * mpc::kBlockFilterTiles * mpc::kFilterTileHalves;
+        a.gram = d.d_gram + static_cast<size_t>(ch) * n_sel * stride;
+        a.gram_stride = stride;
+        a.block_rows = d.d_rows;
+        a.block_row_off = d.d_rowoff;
+        a.quant = d_quant + static_cast<size_t>(ch) * c->K;
+        a.K = c->K;
+        a.channel = ch;
+        a.num_base = d.num_base;
+        a.rows0 = c->dict.block_rows.empty() ? 0 : c->dict.block_rows[0];
+        a.rgb = in.rgb;
+        a.width = in.width;
+        a.height = in.height;
+        a.row_stride = in.row_stride;
+        a.frame_stride = in.frame_stride;
+        a.tile_row_begin = in.tile_row_begin;
+        a.tile_rows = in.tile_rows;
+        a.tiles_x = in.tiles_x;
+        a.vec_in = in.vec_in;
+        a.n_tc = n_tc;
+        a.n_units = static_cast<int>(n_units);
+        a.queue = d.queues + ch;
+        a.pair_p = d.pair_p[ch];
+        a.pair_meta = d.pair_meta[ch];
+        a.pair_e = d.pair_e[ch];
+        a.out = out;
+        hipEvent_t* ev = nullptr;
+        if (c->timing) {
+            const size_t need = c->timing_used + 2;
+            while (c->timing_events.size() < need) {
+                hipEvent_t e;
+                if (hipEventCreate(&e) != hipSuccess) return fail(MPC_ERR_HIP, "hipEventCreate failed");
+                c->timing_events.push_back(e);
+            }
+            ev = c->timing_events.data() + c->timing_used;
+            c->timing_used = need;
+            HIP_TRY(hipEventRecord(ev[0], s));
+        }
+        const int err = mpc::launch_pursuit(a, workgroups, s);
+        if (err != 0) return fail(MPC_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(err)));
+        if (ev) HIP_TRY(hipEventRecord(ev[1], s));
+        HIP_TRY(hipEventRecord(d.done[ch], s));
+        HIP_TRY(hipStreamWaitEvent(caller, d.done[ch], 0));
+    }
+    return MPC_OK;
+}
+
 mpc_status run_pursuit(mpc_context* c, const mpc::FrameInput& in, const mpc::Outputs& out, const double* d_quant,
                        long long total_tc, void* stream) {
+    // MPC_PATH=steps: the step-synchronous kernels of mp_kernels.hip (with MPC_FILTER=0: their exhaustive double sweeps, the
+    // product's own cross-check); default: the persistent kernel
+    if (!steps_path()) return run_persistent(c, in, out, d_quant, total_tc, stream);
     mpc_status st = ensure_workspace(c, total_tc);
     if (st != MPC_OK) return st;
     const mpc::DictDevice dict = dict_device(c);
@@ -293,37 +492,19 @@ mpc_status mpc_context_create(int K, int block_size, double bpp, int device, mpc
             delete c;
             return fail(MPC_ERR_NO_DEVICE, "HIP device %d not available (%d devices visible)", device, ndev);
         }
-        hipError_t e = hipSetDevice(device);
-        std::vector<double> base = mpc::base_padded(c->dict, 2, &c->base_rows_padded);
-        const size_t det_rows = static_cast<size_t>(c->dict.total_detail_rows());
-        // one zero row after the last: the sweep's scalar prefetch reads one row past the rows it correlates
-        std::vector<double> det((3 * det_rows + 1) * mpc::kTileN, 0.0);
-        for (int ch = 0; ch < 3; ++ch)
-            std::memcpy(det.data() + ch * det_rows * mpc::kTileN, c->dict.detail[ch].data(),
-                        det_rows * mpc::kTileN * sizeof(double));
-        if (e == hipSuccess) e = upload(&c->d_base, base.data(), base.size());
-        if (e == hipSuccess) e = upload(&c->d_detail, det.data(), det.size());
+        hipError_t e = acquire_device_dict(device, c->dict, &c->dd);
+        if (e == hipSuccess) {
+            c->d_base = c->dd->d_base;
+            c->d_detail = c->dd->d_detail;
+            c->d_rows = c->dd->d_rows;
+            c->d_rowoff = c->dd->d_rowoff;
+            c->d_base_f32 = c->dd->d_base_f32;
+            c->d_detail_f32 = c->dd->d_detail_f32;
+            c->base_rows_padded = c->dd->base_rows_padded;
+        }
         if (e == hipSuccess) e = upload(&c->d_quant, c->quant.data(), c->quant.size());
         if (e == hipSuccess)
             e = hipMalloc(reinterpret_cast<void**>(&c->d_quant_ring), sizeof(double) * mpc_context::kQuantSlots * 3 * MPC_MAX_K);
-        if (e == hipSuccess) e = upload(&c->d_rows, c->dict.block_rows.data(), c->dict.block_rows.size());
-        if (e == hipSuccess) e = upload(&c->d_rowoff, c->dict.block_row_off.data(), c->dict.block_row_off.size());
-        // split-bfloat16 copies for the filter pass: base rows as 32 tiles of 16 rows, every detail block as 4
-        {
-            const std::vector<uint16_t> base32 = mpc::filter_tiles(c->dict.base.data(), c->dict.num_base, mpc::kBaseFilterTiles);
-            std::vector<uint16_t> det32;
-            det32.reserve(3 * static_cast<size_t>(c->dict.num_base) * mpc::kBlockFilterTiles * mpc::kFilterTileHalves);
-            for (int ch = 0; ch < 3; ++ch)
-                for (int b = 0; b < c->dict.num_base; ++b) {
-                    const std::vector<uint16_t> t = mpc::filter_tiles(
-                        c->dict.detail[ch].data() + static_cast<size_t>(c->dict.block_row_off[b]) * mpc::kTileN,
-                        c->dict.block_rows[b], mpc::kBlockFilterTiles);
-                    det32.insert(det32.end(), t.begin(), t.end());
-                }
-            if (e == hipSuccess) e = upload(&c->d_base_f32, base32.data(), base32.size());
-            if (e == hipSuccess) e = upload(&c->d_detail_f32, det32.data(), det32.size());
-        }
-
         if (e != hipSuccess) {
             mpc_context_destroy(c);
             return fail(MPC_ERR_HIP, "device setup failed: %s", hipGetErrorString(e));
@@ -340,14 +521,8 @@ void mpc_context_destroy(mpc_context* c) {
     if (!c) return;
     if (c->device >= 0) {
         (void)hipSetDevice(c->device);
-        (void)hipFree(c->d_base);
-        (void)hipFree(c->d_detail);
         (void)hipFree(c->d_quant);
         (void)hipFree(c->d_quant_ring);
-        (void)hipFree(c->d_rows);
-        (void)hipFree(c->d_rowoff);
-        (void)hipFree(c->d_base_f32);
-        (void)hipFree(c->d_detail_f32);
         (void)hipFree(c->d_flag);
         (void)hipFree(c->stage);
         if (c->host_stage) (void)hipHostFree(c->host_stage);
