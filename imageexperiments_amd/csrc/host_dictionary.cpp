@@ -533,7 +533,8 @@ std::vector<uint16_t> filter_tiles(const double* rows, int nrows, int tiles, int
             for (int lane = 0; lane < 64; ++lane)
                 for (int j = 0; j < 8; ++j) {
                     const int row = tile * 16 + (lane & 15);
-                    const int k = k_order == 0 ? 32 * kk + 8 * (lane >> 4) + j : 16 * (lane >> 4) + 8 * kk + j;
+                    const int hrow = lane >> 4;
+                    const int k = k_order == 0 ? 32 * kk + 8 * hrow + j : 16 * (hrow ^ (hrow >> 1)) + 8 * kk + j;
                     if (row >= nrows || shadowed[row]) continue;
                     const float x = static_cast<float>(rows[static_cast<size_t>(row) * kTileN + k]);
                     const uint16_t hi = bf16_round(x);

@@ -63,8 +63,9 @@ std::vector<double> base_padded(const Dictionary& d, int pad_rows, int* padded_r
 // A row that is bit-for-bit +-(an earlier row) is left zero: its projection ties with the earlier row's exactly
 // (IEEE negation commutes with every rounding of the dot product), so Select()'s strict '>' never returns it.
 // k_order selects which pixel an operand element holds (the MFMA sums over k in any order as long as both operands
-// agree): 0 = 32*kk + 8*(lane >> 4) + j (the step-synchronous filter kernels), 1 = 16*(lane >> 4) + 8*kk + j (the
-// persistent pursuit kernel: a lane's 16 elements are 16 CONSECUTIVE pixels, which is what its exact evaluation wants).
+// agree): 0 = 32*kk + 8*(lane >> 4) + j (the step-synchronous filter kernels), 1 = 16*pos(lane >> 4) + 8*kk + j with pos = 0, 1, 3, 2
+// (the persistent pursuit kernel: a lane's 16 elements are 16 CONSECUTIVE pixels, which is what its exact evaluation wants;
+// the order of the lane rows is the order in which one-instruction lane swaps pass the running sum on).
 // shadow_out (optional): 1 for every row left zero because it duplicates an earlier one.
 std::vector<uint16_t> filter_tiles(const double* rows, int nrows, int tiles, int k_order = 0,
                                    std::vector<uint8_t>* shadow_out = nullptr);

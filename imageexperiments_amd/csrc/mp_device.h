@@ -161,6 +161,7 @@ struct PursuitArgs {
     unsigned* pair_meta;
     float* pair_e;
     Outputs out;
+    unsigned long long* debug;       // diagnostic builds (-DMPC_STAMPS) only: 24 phase-cycle / event counters; else null
 };
 
 int launch_pursuit(const PursuitArgs& args, int workgroups, void* stream);

@@ -32,14 +32,15 @@ namespace mpc {
 namespace {
 
 constexpr int N = 64;
-constexpr int kGroups = 2;                       // column groups (16 tile-channels each) per wave
-constexpr int kWaves = 8;                        // waves per workgroup (two per SIMD)
+constexpr int kGroups = 1;                       // column groups (16 tile-channels each) per wave
+constexpr int kWaves = 12;                       // waves per workgroup (three per SIMD)
 constexpr int kTilesLds = kBaseFilterTiles + kBlockFilterTiles;     // 36
 constexpr double W_R = 0.299, W_G = 0.587, W_B = 0.114;            // ImageHelper/inc/misc.h:7-11
 constexpr double U_SCALE = 0.436 / (1.0 - 0.114);
 constexpr double V_SCALE = 0.615 / (1.0 - 0.299);
 constexpr float kSlack = 0x1p-13f;               // E = kSlack |r~| + kAbs bounds the split-bf16 MFMA error (mp_kernels.hip)
 constexpr float kAbs = 0x1p-100f;
+constexpr float kHuge = 1.0e30f;                 // beyond this the f32 side may overflow: the tile-channel is evaluated exhaustively
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
@@ -59,37 +60,111 @@ __device__ __forceinline__ unsigned short bf16_of(float x)          // v_cvt_pk_
     return __builtin_bit_cast(unsigned short, b);
 }
 
-// The two largest values a lane has seen and the row (code) of the largest; sum poisons on NaN / infinity.
-struct TopTwo {
-    float m1 = 0.0f, m2 = 0.0f, sum = 0.0f;
-    int row = -1;
-    __device__ __forceinline__ void see(float a, int r)             // a >= 0 (or NaN)
+// ---- the four lanes of a slot are l, l^16, l^32, l^48: exchanges between them as VALU lane swaps (no LDS crossbar) -------
+// v_permlane16_swap(x, x): [0] = x of lane - 16 in odd rows of 16, [1] = x of lane + 16 in even rows (else own x);
+// v_permlane32_swap(x, x): [0] = x of lane - 32 in lanes 32..63, [1] = x of lane + 32 in lanes 0..31 (else own x).
+template <class Op>
+__device__ __forceinline__ unsigned reduce4_u(unsigned x, Op op)
+{
+    const auto a = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+    const unsigned m = op(a[0], a[1]);
+    const auto b = __builtin_amdgcn_permlane32_swap(m, m, false, false);
+    return op(b[0], b[1]);
+}
+__device__ __forceinline__ float reduce4_max(float x)
+{
+    return __uint_as_float(reduce4_u(__float_as_uint(x), [](unsigned p, unsigned q) {
+        return __float_as_uint(__builtin_amdgcn_fmed3f(__uint_as_float(p), __uint_as_float(q), __builtin_inff()));
+    }));
+}
+__device__ __forceinline__ unsigned reduce4_add(unsigned x) { return reduce4_u(x, [](unsigned p, unsigned q) { return p + q; }); }
+__device__ __forceinline__ double reduce4_add(double x)
+{
+    unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    const double m = __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+    lo = (unsigned)__double2loint(m); hi = (unsigned)__double2hiint(m);
+    const auto c = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto d = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double((int)d[0], (int)c[0]) + __hiloint2double((int)d[1], (int)c[1]);
+}
+// which of the two results of a swap(x, x) is the OTHER lane's value
+__device__ __forceinline__ double from_prev16(double x)             // odd rows: x of lane - 16
+{
+    const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[0], (int)a[0]);
+}
+__device__ __forceinline__ double from_next16(double x)             // even rows: x of lane + 16
+{
+    const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[1], (int)a[1]);
+}
+__device__ __forceinline__ double from_prev32(double x)             // lanes 32..63: x of lane - 32
+{
+    const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[0], (int)a[0]);
+}
+__device__ __forceinline__ double from_next32(double x)             // lanes 0..31: x of lane + 32
+{
+    const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[1], (int)a[1]);
+}
+
+// Lane row h (= lane >> 4) holds the pixels 16 * pos(h) .. + 15 with pos = 0, 1, 3, 2: the running sum of a dot product then
+// travels row 0 -> 1 (16-lane swap) -> 3 (32-lane swap) -> 2 (16-lane swap), every hop one VALU lane swap.
+__device__ __forceinline__ int pos_of(int h) { return h ^ (h >> 1); }
+
+// Sum of the 64 terms held 16 per lane by the four lanes of a slot, in pixel order 0..63, starting from 0.0 (the reference's
+// `tot = 0; tot += l * r`, mathmatrix.cpp:436-444); the result is returned in all four lanes.
+__device__ __forceinline__ double chain_sum(const double (&term)[16], int h)
+{
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += term[i];                      // pixels 0..15: meaningful in row 0
+    double u = from_prev16(t);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) u += term[i];                      // 16..31: row 1
+    t = h == 1 ? u : t;
+    u = from_prev32(t);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) u += term[i];                      // 32..47: row 3
+    t = h == 3 ? u : t;
+    u = from_next16(t);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) u += term[i];                      // 48..63: row 2 holds the whole sum
+    t = h == 2 ? u : t;
+    u = from_prev16(t);
+    t = h == 3 ? u : t;                                             // rows 2 and 3
+    u = from_next32(t);
+    return h < 2 ? u : t;
+}
+
+// The two largest approximations a lane has seen, as KEYS: the value's bits with the low mantissa bits replaced by a code
+// that names the row (so one v_and_or + two v_med3 track value and row together, and the runner-up's row is known as well).
+// A key read as a float is >= the truncated value and < value * (1 + 2^-(23 - bits)): callers widen their thresholds by that.
+// Values are finite and >= 0 (callers divert NaN / infinity / overflow before relying on it), so float order = key order.
+struct TopKeys {
+    float k1 = 0.0f, k2 = 0.0f;                                     // k1 >= k2
+    // mask and code in registers: one v_and_or_b32; keys are non-negative floats, so the integer maximum is the float maximum
+    __device__ __forceinline__ void see(unsigned value_bits, unsigned keep_mask, unsigned code)
     {
-        row = a > m1 ? r : row;
-        m2 = __builtin_amdgcn_fmed3f(m1, m2, a);
-        m1 = fmaxf(m1, a);
-        sum += a;
-    }
-    // over the four lanes of a slot: top, runner-up (a tie for the top counts), does this lane own the unique top, NaN/Inf seen
-    __device__ __forceinline__ void across(float& top, float& second, bool& mine, bool& odd) const
-    {
-        top = fmaxf(m1, __shfl_xor(m1, 16));
-        top = fmaxf(top, __shfl_xor(top, 32));
-        const bool at_top = m1 == top;
-        int n_top = at_top ? 1 : 0;
-        n_top += __shfl_xor(n_top, 16);
-        n_top += __shfl_xor(n_top, 32);
-        float rest = at_top ? m2 : m1;
-        rest = fmaxf(rest, __shfl_xor(rest, 16));
-        rest = fmaxf(rest, __shfl_xor(rest, 32));
-        second = n_top > 1 ? top : rest;
-        mine = at_top && n_top == 1;
-        int o = !(sum <= 3.4028234663852886e38f) ? 1 : 0;
-        o |= __shfl_xor(o, 16);
-        o |= __shfl_xor(o, 32);
-        odd = o != 0;
+        const unsigned key = (value_bits & keep_mask) | code;
+        k2 = __builtin_amdgcn_fmed3f(k1, k2, __uint_as_float(key));
+        const unsigned k1b = __float_as_uint(k1);
+        k1 = __uint_as_float(k1b > key ? k1b : key);
     }
 };
+constexpr unsigned kKeepRow = 0x7FFFFF80u;        // |value| with 7 code bits: tile (5) and row within the lane's four (2)
+constexpr unsigned kKeepPair = 0x7FFFFE00u;      // |value| with 9 code bits: pair (5), tile (2), row (2)
 
 // Survivors of one lane waiting for their exact evaluation.  code = segment << 16 | pair << 11 | row; segment 0 = base
 // rows, 1 = DetailBasis[0], 2 = pair.  More than four on one lane: the tile-channel falls back to evaluating every row.
@@ -107,18 +182,17 @@ struct Survivors {
 
 // State of one tile-channel, replicated in the four lanes of its slot.
 struct TileChannel {
-    int rec = 0;                 // record index (counts[rec], choices[rec * K + step])
     int prev_id = 0;
     int next_off = 0;            // dictionary index where the next unlocked block starts (510 + rows appended so far)
     int off0 = 0;                // index of DetailBasis[0]'s first row once unlocked
     int npairs = 0;
     int fresh = -1;              // pair created by the last step: its approximations come from the MFMAs, not from G
-    int fresh_blk = 0;
+    unsigned pk0 = 0, pk1 = 0;   // block (9 bits) | rows (7 bits) of pairs 0, 1 and 2, 3: the common case needs no meta load
     unsigned swept = 0;
     bool has0 = false, live = false;
     double coeff = 0.0;          // pending residual update (0 = none): r -= coeff * row
     int sel_g = 0;               // Gram row of the chosen atom (base row, or 510 + detail row)
-    const double* sel_row = nullptr;
+    __device__ __forceinline__ unsigned packed(int p) const { return ((p < 2 ? pk0 : pk1) >> (16 * (p & 1))) & 0xFFFFu; }
 };
 
 __device__ __forceinline__ void load16(double (&x)[16], const double* p)
@@ -132,52 +206,61 @@ __device__ __forceinline__ void load16(double (&x)[16], const double* p)
     }
 }
 
-// Sum of the 64 terms held 16 per lane by the four lanes (h = 0..3) of a slot, in pixel order 0..63, starting from 0.0:
-// lane h = 0 adds its 16, hands the running sum to h = 1, and so on; the result is broadcast to the four lanes.
-__device__ __forceinline__ double chain_sum(const double (&term)[16], int lane)
-{
-    const int h = lane >> 4;
-    double t = 0.0;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) t += term[i];
-#pragma unroll
-    for (int phase = 1; phase < 4; ++phase) {
-        double u = __shfl_up(t, 16);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) u += term[i];
-        t = h >= phase ? u : t;
-    }
-    return __shfl(t, (lane & 15) + 48);
-}
-
-__device__ __forceinline__ void keep_better(double& v, int& i, int& sel, const double*& ptr, double ov, int oi, int osel, const double* optr)
+__device__ __forceinline__ void keep_better(double& v, int& i, int& sel, double ov, int oi, int osel)
 {
     const double a = __builtin_fabs(ov), b = __builtin_fabs(v);
     if (oi >= 0 && (a > b || (a == b && i >= 0 && oi < i))) {       // start: v = 0.0, i = -1: a strict '>' 0 like Select()
-        v = ov; i = oi; sel = osel; ptr = optr;
+        v = ov; i = oi; sel = osel;
     }
 }
+
+// In-kernel phase stamps: diagnostic builds only (-DMPC_STAMPS, tools/stamps.sh); the product build has none.
+#ifdef MPC_STAMPS
+#define STAMP(i)                                              \
+    {                                                         \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        stamp_acc[i] += now_ - stamp_prev;                    \
+        stamp_prev = now_;                                    \
+    }
+#define COUNT(i, n) stamp_acc[i] += (unsigned long long)(n);
+#else
+#define STAMP(i)
+#define COUNT(i, n)
+#endif
 
 }  // namespace
 
 // --------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64 * kWaves, 2) void mp_pursuit_kernel(const PursuitArgs a)
+__global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(const PursuitArgs a)
 {
+#ifdef MPC_STAMPS
+    unsigned long long stamp_acc[24];
+    for (int i = 0; i < 24; ++i) stamp_acc[i] = 0;
+    unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
+#endif
     __shared__ uint4 s_tiles[kTilesLds * 256];                      // [tile][operand q][lane], 4 KiB per tile
+    __shared__ int s_rows[512], s_rowoff[512];                      // block_rows / block_row_off
+    __shared__ unsigned s_touch[64 * kWaves];                       // landing zone of the cache-touch loads (never read)
     {
         const uint4* src_base = reinterpret_cast<const uint4*>(a.base_tiles);
         const uint4* src_blk0 = reinterpret_cast<const uint4*>(a.block_tiles);      // block 0 = the first four tiles
         for (int i = threadIdx.x; i < kTilesLds * 256; i += 64 * kWaves)
             s_tiles[i] = i < kBaseFilterTiles * 256 ? src_base[i] : src_blk0[i - kBaseFilterTiles * 256];
+        for (int i = threadIdx.x; i < 512; i += 64 * kWaves) {
+            s_rows[i] = i < a.num_base ? a.block_rows[i] : 0;
+            s_rowoff[i] = i < a.num_base ? a.block_row_off[i] : 0;
+        }
     }
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int slot = lane & 15, h = lane >> 4;
+    const int pix0 = 16 * pos_of(h);                                // first of this lane's 16 consecutive pixels
     const long long wave_global = (long long)blockIdx.x * kWaves + wave;
     float* const my_p = a.pair_p + wave_global * (kGroups * 16 * kMaxPairs * 64);
     unsigned* const my_meta = a.pair_meta + wave_global * (kGroups * 16 * kMaxPairs * 2);
     float* const my_e = a.pair_e + wave_global * (kGroups * 16 * kMaxPairs);
+    unsigned* const my_touch = s_touch + 64 * wave;
     const int K = a.K, ch = a.channel;
 
     int unit[kGroups], step[kGroups];
@@ -186,6 +269,26 @@ __global__ __launch_bounds__(64 * kWaves, 2) void mp_pursuit_kernel(const Pursui
 #pragma unroll
     for (int g = 0; g < kGroups; ++g) { unit[g] = -1; step[g] = 0; }
     bool queue_empty = false;
+
+    auto tile_mfma = [&](const uint4 (&av)[4], const bf16x8 (&hi)[2], const bf16x8 (&lo)[2]) {
+        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 ah, al;
+            __builtin_memcpy(&ah, &av[2 * kk + 0], 16);
+            __builtin_memcpy(&al, &av[2 * kk + 1], 16);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, hi[kk], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, lo[kk], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, hi[kk], acc, 0, 0, 0);
+        }
+        return acc;
+    };
+    // record index of this lane's tile-channel in unit u: counts[rec], choices[rec * K + step]
+    auto rec_of = [&](int u) { const long long t = (long long)u * 16 + slot; return a.vec_in ? t : t * 3 + ch; };
+    auto lds_tile = [&](uint4 (&dst)[4], int t) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dst[q] = s_tiles[t * 256 + q * 64 + lane];
+    };
 
     for (;;) {
         // ---- (1) refill empty groups from the queue ---------------------------------------------------------------
@@ -202,46 +305,69 @@ __global__ __launch_bounds__(64 * kWaves, 2) void mp_pursuit_kernel(const Pursui
             TileChannel s;
             s.live = t < a.n_tc;
             s.next_off = a.num_base;
+            const long long ts = s.live ? t : 0;                    // loads below are unconditional: always a valid address
             if (a.vec_in) {
-                s.rec = (int)t;
-                if (s.live) load16(r[g], a.vec_in + t * N + 16 * h);
-                else
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) r[g][i] = 0.0;
+                load16(r[g], a.vec_in + ts * N + pix0);
             } else {
-                s.rec = (int)(t * 3 + ch);
                 const int tiles_per_frame = a.tiles_x * a.tile_rows;
-                const int frame = (int)(t / tiles_per_frame);
-                const int tile = (int)(t - (long long)frame * tiles_per_frame);
+                const int frame = (int)(ts / tiles_per_frame);
+                const int tile = (int)(ts - (long long)frame * tiles_per_frame);
                 const int tx = tile / a.tile_rows, ty = a.tile_row_begin + (tile - tx * a.tile_rows);
+                const uint8_t* img = a.rgb + (long long)frame * a.frame_stride;
+                unsigned char px[16][3];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {                      // block index dx + 8 dy = pix0 + i
+                    const int x = tx * 8 + (i & 7), y = ty * 8 + (pix0 >> 3) + (i >> 3);
+                    const int xc = x < a.width ? x : a.width - 1, yc = y < a.height ? y : a.height - 1;
+                    const uint8_t* p = img + (long long)yc * a.row_stride + 3 * xc;
+                    px[i][0] = p[0]; px[i][1] = p[1]; px[i][2] = p[2];
+                }
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const int px = tx * 8 + (i & 7), py = ty * 8 + 2 * h + (i >> 3);       // block index dx + 8 dy = 16h + i
-                    double v = 0.0;                                                      // zero fill (CompressedImage.cpp:548-552)
-                    if (s.live && px < a.width && py < a.height) {
-                        const uint8_t* p = a.rgb + (long long)frame * a.frame_stride + (long long)py * a.row_stride + 3 * px;
-                        const double red = (double)p[0], green = (double)p[1], blue = (double)p[2];
-                        const double Y = (W_R * red + W_G * green + W_B * blue);         // misc.cpp:12-21, same expression order
-                        v = ch == 0 ? Y : (ch == 1 ? (U_SCALE * (blue - Y)) : (V_SCALE * (red - Y)));
-                    }
-                    r[g][i] = v;
+                    const int x = tx * 8 + (i & 7), y = ty * 8 + (pix0 >> 3) + (i >> 3);
+                    const double red = (double)px[i][0], green = (double)px[i][1], blue = (double)px[i][2];
+                    const double Y = (W_R * red + W_G * green + W_B * blue);            // misc.cpp:12-21, same expression order
+                    const double v = ch == 0 ? Y : (ch == 1 ? (U_SCALE * (blue - Y)) : (V_SCALE * (red - Y)));
+                    r[g][i] = (x < a.width && y < a.height) ? v : 0.0;                 // zero fill (CompressedImage.cpp:548-552)
                 }
             }
+            if (!s.live)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) r[g][i] = 0.0;
             tc[g] = s;
         });
         bool any_unit = false;
 #pragma unroll
         for (int g = 0; g < kGroups; ++g) any_unit = any_unit || unit[g] >= 0;
         if (!any_unit) break;
+        STAMP(0)
+        COUNT(12, 1)
+        static_for<kGroups>([&](auto gc) { COUNT(16, __popcll(__ballot(tc[decltype(gc)::value].live && unit[decltype(gc)::value] >= 0))) });
 
-        // ---- (2) B operands from the residuals; error bound of this step's MFMA approximations ----------------------
+        // ---- (2) the Gram update of pair 0 of both groups needs P, G and E from memory: in flight while the B operands are built
+        float4 pv0[kGroups][4], gv0[kGroups][4];
+        float E0[kGroups];
+        bool on0[kGroups], upd0[kGroups];
+        unsigned info0[kGroups];
+#pragma unroll
+        for (int g = 0; g < kGroups; ++g) {
+            on0[g] = unit[g] >= 0 && tc[g].live && tc[g].npairs > 0 && tc[g].fresh != 0;
+            upd0[g] = on0[g] && tc[g].coeff != 0.0;
+            info0[g] = tc[g].packed(0);
+            const long long pi = (long long)(g * 16 + slot) * kMaxPairs;
+            const float4* pp = reinterpret_cast<const float4*>(my_p + pi * 64 + 4 * h);
+            const float4* gp = reinterpret_cast<const float4*>(a.gram + (upd0[g] ? (long long)tc[g].sel_g * a.gram_stride + (int)(info0[g] & 511u) * 64 : 0) + 4 * h);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { pv0[g][t] = pp[4 * t]; gv0[g][t] = gp[4 * t]; }
+            E0[g] = my_e[pi];
+        }
+
+        // ---- (2a) B operands from the residuals; error bound of this step's MFMA approximations ----------------------
         bf16x8 bh[kGroups][2], bl[kGroups][2];
         float Eb[kGroups], rnorm[kGroups];
-        bool nz[kGroups];
+        bool nz[kGroups], odd[kGroups];
         static_for<kGroups>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
-            Eb[g] = 0.0f; rnorm[g] = 0.0f; nz[g] = false;
-            if (unit[g] < 0) return;
             double ss = 0.0;
             bool nzl = false;
 #pragma unroll
@@ -255,152 +381,199 @@ __global__ __launch_bounds__(64 * kWaves, 2) void mp_pursuit_kernel(const Pursui
                 bh[g][i >> 3][i & 7] = (short)hb;
                 bl[g][i >> 3][i & 7] = (short)lb;
             }
-            ss += __shfl_xor(ss, 16);
-            ss += __shfl_xor(ss, 32);
-            int nzi = nzl ? 1 : 0;
-            nzi |= __shfl_xor(nzi, 16);
-            nzi |= __shfl_xor(nzi, 32);
-            nz[g] = nzi != 0;
+            ss = reduce4_add(ss);
+            nz[g] = reduce4_add(nzl ? 1u : 0u) != 0u;
             rnorm[g] = (float)__builtin_sqrt(ss) * 1.0000002f;
             Eb[g] = kSlack * rnorm[g] + kAbs;
+            odd[g] = !(rnorm[g] < kHuge);                           // NaN, infinity or large enough to overflow the f32 side
         });
+        STAMP(1)
 
-        auto tile_mfma = [&](const uint4 (&av)[4], const bf16x8 (&hi)[2], const bf16x8 (&lo)[2]) {
-            f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        // ---- (2b) pairs: P_b -= float(c) * G[a][b] for the atom a chosen last step; top two upper bounds |P_b| + E as keys
+        TopKeys tp[kGroups];
+        float lbmax[kGroups];
+        bool oddp[kGroups];
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                bf16x8 ah, al;
-                __builtin_memcpy(&ah, &av[2 * kk + 0], 16);
-                __builtin_memcpy(&al, &av[2 * kk + 1], 16);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, hi[kk], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, lo[kk], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, hi[kk], acc, 0, 0, 0);
+        for (int g = 0; g < kGroups; ++g) { lbmax[g] = -3.0e38f; oddp[g] = false; }
+        auto pair_update = [&](auto gc, int p, bool upd, unsigned info, float4 (&pv)[4], const float4 (&gv)[4], float E) {
+            constexpr int g = decltype(gc)::value;
+            const long long pi = (long long)(g * 16 + slot) * kMaxPairs + p;
+            const int rows = (int)((info >> 9) & 127u);
+            if (upd) {
+                const float c32 = (float)tc[g].coeff;
+                float4* pp = reinterpret_cast<float4*>(my_p + pi * 64 + 4 * h);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    pv[t].x = fmaf(-c32, gv[t].x, pv[t].x);
+                    pv[t].y = fmaf(-c32, gv[t].y, pv[t].y);
+                    pv[t].z = fmaf(-c32, gv[t].z, pv[t].z);
+                    pv[t].w = fmaf(-c32, gv[t].w, pv[t].w);
+                    pp[4 * t] = pv[t];
+                }
+                // |P_b - <b, r>| grows by at most 2^-23 |c| (rounding of c and of G) + 2^-24 (|r| + E) (the fma's result)
+                E = (E + 0x1p-21f * (fabsf(c32) + rnorm[g])) * 1.000001f;
+                if (h == 0) my_e[pi] = E;
+                oddp[g] = oddp[g] || !(fabsf(c32) < kHuge);
             }
-            return acc;
+            oddp[g] = oddp[g] || !(E < kHuge);
+            // rows 62 and 63 of a block can be pads (blocks have 62 or 63 rows): lane row h = 3, tile 3, v = 2, 3.  Their P and G
+            // are exactly 0; their upper bound must be 0 too (not E), or a pad could pass for a survivor.
+            const bool pad2 = h == 3 && rows < 63, pad3 = h == 3 && rows < 64;
+            const unsigned keepp = __builtin_amdgcn_readfirstlane((int)(kKeepPair | (lane >> 8)));
+            float biggest = 0.0f;                                   // of this pair's |P|: its lower bound is biggest - E
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float vals[4] = {pv[t].x, pv[t].y, pv[t].z, pv[t].w};
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const float m = fabsf(vals[v]);
+                    float ub = m + E;
+                    if (t == 3 && v == 2) ub = pad2 ? 0.0f : ub;
+                    if (t == 3 && v == 3) ub = pad3 ? 0.0f : ub;
+                    tp[g].see(__float_as_uint(ub), keepp, (unsigned)((p << 4) | (t << 2) | v));
+                    biggest = __builtin_amdgcn_fmed3f(biggest, m, __builtin_inff());
+                }
+            }
+            lbmax[g] = __builtin_amdgcn_fmed3f(lbmax[g], biggest - E, __builtin_inff());
         };
+        static_for<kGroups>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            if (on0[g]) pair_update(gc, 0, upd0[g], info0[g], pv0[g], gv0[g], E0[g]);
+        });
+#pragma unroll 1
+        for (int p = 1;; ++p) {                                     // further pairs: both groups' loads of a round issued together
+            bool on[kGroups];
+            bool any = false;
+#pragma unroll
+            for (int g = 0; g < kGroups; ++g) {
+                on[g] = unit[g] >= 0 && tc[g].live && p < tc[g].npairs && p != tc[g].fresh;
+                any = any || (unit[g] >= 0 && tc[g].live && p < tc[g].npairs);
+            }
+            if (!__ballot(any)) break;
+            unsigned info[kGroups];
+            float4 pv[kGroups][4], gv[kGroups][4];
+            float E[kGroups];
+            bool upd[kGroups];
+#pragma unroll
+            for (int g = 0; g < kGroups; ++g) {
+                const long long pi = (long long)(g * 16 + slot) * kMaxPairs + (on[g] ? p : 0);
+                info[g] = p < 4 ? tc[g].packed(p) : (my_meta[2 * pi] & 0xFFFFu);
+                upd[g] = on[g] && tc[g].coeff != 0.0;
+                const float4* pp = reinterpret_cast<const float4*>(my_p + pi * 64 + 4 * h);
+                const float4* gp = reinterpret_cast<const float4*>(a.gram + (upd[g] ? (long long)tc[g].sel_g * a.gram_stride + (int)(info[g] & 511u) * 64 : 0) + 4 * h);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { pv[g][t] = pp[4 * t]; gv[g][t] = gp[4 * t]; }
+                E[g] = my_e[pi];
+            }
+            static_for<kGroups>([&](auto gc) {
+                constexpr int g = decltype(gc)::value;
+                if (on[g]) pair_update(gc, p, upd[g], info[g], pv[g], gv[g], E[g]);
+            });
+        }
+        STAMP(2)
 
-        // ---- (2b) a pair created by the last step: first approximations of its 64 rows from the block's filter tiles ---
+        // ---- (2c) a pair created by the last step: first approximations of its 64 rows from the block's filter tiles (their
+        //      lines were pulled towards the cache when the pair was created)
         static_for<kGroups>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
             if (unit[g] < 0) return;
-            unsigned long long pend = __ballot(tc[g].live && tc[g].fresh >= 0 && h == 0);
-            float pnew[16];
+            const bool mine = tc[g].live && tc[g].fresh >= 0;
+            unsigned long long pend = __ballot(mine && h == 0);
+            if (!pend) return;
+            unsigned fresh_info = 0;
+            if (mine)
+                fresh_info = (tc[g].fresh < 4 ? tc[g].packed(tc[g].fresh) : my_meta[2 * ((long long)(g * 16 + slot) * kMaxPairs + tc[g].fresh)]) & 0xFFFFu;
+            float4 pnew[4];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) pnew[i] = 0.0f;
+            for (int t = 0; t < 4; ++t) pnew[t] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             while (pend) {
                 const int src = __builtin_ctzll(pend);
                 pend &= pend - 1;
-                const int blk = __builtin_amdgcn_readlane(tc[g].fresh_blk, src);
+                const int blk = __builtin_amdgcn_readlane((int)(fresh_info & 511u), src);
                 const uint4* tiles = reinterpret_cast<const uint4*>(a.block_tiles) + (long long)blk * (kBlockFilterTiles * 256) + lane;
 #pragma unroll
-                for (int t = 0; t < kBlockFilterTiles; ++t) {
-                    uint4 av[4];
+                for (int t2 = 0; t2 < kBlockFilterTiles; t2 += 2) {
+                    uint4 av[2][4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) av[q] = tiles[t * 256 + q * 64];
-                    const f32x4 acc = tile_mfma(av, bh[g], bl[g]);
-                    if (slot == src) {
+                    for (int t = 0; t < 2; ++t)
 #pragma unroll
-                        for (int v = 0; v < 4; ++v) pnew[4 * t + v] = acc[v];
+                        for (int q = 0; q < 4; ++q) av[t][q] = tiles[(t2 + t) * 256 + q * 64];    // two tiles (8 KiB) in flight
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const f32x4 acc = tile_mfma(av[t], bh[g], bl[g]);
+                        if (slot == src) pnew[t2 + t] = make_float4(acc[0], acc[1], acc[2], acc[3]);
                     }
                 }
             }
-            if (tc[g].live && tc[g].fresh >= 0) {
+            if (mine) {
                 float4* dst = reinterpret_cast<float4*>(my_p + ((long long)(g * 16 + slot) * kMaxPairs + tc[g].fresh) * 64 + 4 * h);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) dst[4 * t] = make_float4(pnew[4 * t], pnew[4 * t + 1], pnew[4 * t + 2], pnew[4 * t + 3]);
+                for (int t = 0; t < 4; ++t) dst[4 * t] = pnew[t];
                 if (h == 0) my_e[(g * 16 + slot) * kMaxPairs + tc[g].fresh] = Eb[g];
+                const float4 none[4] = {};
+                pair_update(gc, tc[g].fresh, false, fresh_info, pnew, none, Eb[g]);
             }
         });
+        STAMP(3)
 
-        // ---- (3) pass 1 over the LDS tiles: top two approximations per lane, base rows and DetailBasis[0] apart ----------
-        TopTwo tb[kGroups], td[kGroups];
-        bool want0[kGroups];
-#pragma unroll
-        for (int g = 0; g < kGroups; ++g) want0[g] = unit[g] >= 0 && __ballot(tc[g].live && tc[g].has0) != 0;
+        // ---- (3) pass 1 over the LDS tiles: top two approximations per lane as keys, base rows and DetailBasis[0] apart.  Both
+        //      groups always run (an empty group computes on stale registers and is ignored): no branch between the MFMAs of a
+        //      tile and the tracking of the previous tile's results, which fills their shadow.  No global memory in here: the
+        //      stores of the pair updates drain meanwhile.
+        TopKeys tb[kGroups], td[kGroups];
         bool any0 = false;
 #pragma unroll
-        for (int g = 0; g < kGroups; ++g) any0 = any0 || want0[g];
+        for (int g = 0; g < kGroups; ++g) any0 = any0 || (unit[g] >= 0 && __ballot(tc[g].live && tc[g].has0) != 0);
         {
-            const int last = any0 ? kTilesLds : kBaseFilterTiles;
-            uint4 cur[4], nxt[4];
+            uint4 ta[4], tbuf[4];
+            f32x4 acc[kGroups], prev[kGroups];
+            const unsigned keep = __builtin_amdgcn_readfirstlane((int)(kKeepRow | (lane >> 8)));      // in a register: v_and_or_b32
+            auto track = [&](TopKeys (&trk)[kGroups], const f32x4 (&val)[kGroups], unsigned code0) {
+                unsigned code[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) cur[q] = s_tiles[q * 64 + lane];
-            for (int t = 0; t < last; ++t) {
-                const int tn = t + 1 < last ? t + 1 : t;
+                for (int v = 0; v < 4; ++v) code[v] = code0 + v;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) nxt[q] = s_tiles[tn * 256 + q * 64 + lane];
-                const bool is_base = t < kBaseFilterTiles;
-                const int row0 = (is_base ? t : t - kBaseFilterTiles) * 16 + 4 * h;
-                static_for<kGroups>([&](auto gc) {
-                    constexpr int g = decltype(gc)::value;
-                    if (unit[g] < 0 || (!is_base && !want0[g])) return;
-                    const f32x4 acc = tile_mfma(cur, bh[g], bl[g]);
-                    if (is_base) {
+                for (int g = 0; g < kGroups; ++g)
 #pragma unroll
-                        for (int v = 0; v < 4; ++v) tb[g].see(fabsf(acc[v]), row0 + v);
-                    } else {
+                    for (int v = 0; v < 4; ++v) trk[g].see(__float_as_uint(val[g][v]), keep, code[v]);
+            };
+            lds_tile(ta, 0);
+            lds_tile(tbuf, 1);
 #pragma unroll
-                        for (int v = 0; v < 4; ++v) td[g].see(fabsf(acc[v]), row0 + v);
-                    }
-                });
+            for (int g = 0; g < kGroups; ++g) prev[g] = tile_mfma(ta, bh[g], bl[g]);
+#pragma unroll 1
+            for (int t = 1; t < kBaseFilterTiles - 1; t += 2) {     // tiles t (in tbuf) and t + 1 (in ta): no register copies
+                lds_tile(ta, t + 1);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
+                for (int g = 0; g < kGroups; ++g) acc[g] = tile_mfma(tbuf, bh[g], bl[g]);
+                track(tb, prev, 4 * (t - 1));
+                lds_tile(tbuf, t + 2);                              // t + 2 <= 32: DetailBasis[0]'s first tile is always resident
+#pragma unroll
+                for (int g = 0; g < kGroups; ++g) prev[g] = tile_mfma(ta, bh[g], bl[g]);
+                track(tb, acc, 4 * t);
+            }
+            // tiles 0 .. 30 are done or in `prev` (tile 30); tile 31 is in tbuf
+#pragma unroll
+            for (int g = 0; g < kGroups; ++g) acc[g] = tile_mfma(tbuf, bh[g], bl[g]);
+            track(tb, prev, 4 * (kBaseFilterTiles - 2));
+            track(tb, acc, 4 * (kBaseFilterTiles - 1));
+            if (any0) {
+#pragma unroll 1
+                for (int t = 0; t < kBlockFilterTiles; ++t) {
+                    lds_tile(ta, kBaseFilterTiles + t);
+#pragma unroll
+                    for (int g = 0; g < kGroups; ++g) acc[g] = tile_mfma(ta, bh[g], bl[g]);
+                    track(td, acc, 4 * t);
+                }
             }
         }
+        STAMP(4)
 
-        // ---- (4) pairs: Gram update of the kept approximations, top two of their upper bounds ----------------------------
-        TopTwo tp[kGroups];
-        float lbmax[kGroups];
-        static_for<kGroups>([&](auto gc) {
-            constexpr int g = decltype(gc)::value;
-            lbmax[g] = -3.0e38f;
-            if (unit[g] < 0) return;
-            const float c32 = (float)tc[g].coeff;
-            const float grow = 0x1p-21f * (fabsf(c32) + rnorm[g]);
-            for (int p = 0; __ballot(tc[g].live && p < tc[g].npairs) != 0; ++p) {
-                if (!(tc[g].live && p < tc[g].npairs)) continue;
-                const long long pi = (long long)(g * 16 + slot) * kMaxPairs + p;
-                const unsigned meta = my_meta[2 * pi];
-                const int blk = (int)(meta & 511u), rows = (int)((meta >> 9) & 127u);
-                float4* pp = reinterpret_cast<float4*>(my_p + pi * 64 + 4 * h);
-                float4 pv[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) pv[t] = pp[4 * t];
-                float E = my_e[pi];
-                if (p != tc[g].fresh && tc[g].coeff != 0.0) {
-                    const float4* gp = reinterpret_cast<const float4*>(a.gram + (long long)tc[g].sel_g * a.gram_stride + blk * 64 + 4 * h);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const float4 gv = gp[4 * t];
-                        pv[t].x = fmaf(-c32, gv.x, pv[t].x);
-                        pv[t].y = fmaf(-c32, gv.y, pv[t].y);
-                        pv[t].z = fmaf(-c32, gv.z, pv[t].z);
-                        pv[t].w = fmaf(-c32, gv.w, pv[t].w);
-                        pp[4 * t] = pv[t];
-                    }
-                    E = (E + grow) * 1.000001f;
-                    if (h == 0) my_e[pi] = E;
-                }
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const float vals[4] = {pv[t].x, pv[t].y, pv[t].z, pv[t].w};
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        const int row = 16 * t + 4 * h + v;
-                        const float m = fabsf(vals[v]);
-                        const bool real = row < rows;
-                        tp[g].see(real ? m + E : 0.0f, (p << 11) | row);
-                        lbmax[g] = fmaxf(lbmax[g], real ? m - E : -3.0e38f);
-                    }
-                }
-            }
-            lbmax[g] = fmaxf(lbmax[g], __shfl_xor(lbmax[g], 16));
-            lbmax[g] = fmaxf(lbmax[g], __shfl_xor(lbmax[g], 32));
-        });
-
-        // ---- (5) thresholds; where the runner-up stays below, the single survivor of a segment is known already ----------
+        // ---- (5) thresholds and survivors --------------------------------------------------------------------------------
         // Every row's exact |p| lies in [|a| - E, |a| + E] (E = Eb for MFMA rows, the pair's own bound otherwise).  With
-        // T = the largest lower bound, the row Select() returns -- and every row tying with it -- has |a| + E >= T.
+        // T = the largest lower bound, the row Select() returns -- and every row tying with it -- has |a| + E >= T.  A key
+        // stands for a value in [key & mask, key * (1 + 2^-16)] (2^-14 for pairs): thresholds on keys are lowered accordingly.
+        // A lane whose runner-up key also reaches the threshold may hold more than two survivors: pass 2 / rescan lists them.
         Survivors sv[kGroups];
         float thr_b[kGroups], T[kGroups];
         bool pass2[kGroups], rescan[kGroups];
@@ -408,49 +581,58 @@ __global__ __launch_bounds__(64 * kWaves, 2) void mp_pursuit_kernel(const Pursui
             constexpr int g = decltype(gc)::value;
             pass2[g] = false; rescan[g] = false; thr_b[g] = 0.0f; T[g] = 0.0f;
             if (unit[g] < 0) return;
-            float top_b, second_b, top_d, second_d, top_p, second_p;
-            bool mine_b, mine_d, mine_p, odd_b, odd_d, odd_p;
-            tb[g].across(top_b, second_b, mine_b, odd_b);
-            td[g].across(top_d, second_d, mine_d, odd_d);
-            tp[g].across(top_p, second_p, mine_p, odd_p);
             const bool has0 = tc[g].has0, hasp = tc[g].npairs > 0;
+            const float top_b = __uint_as_float(__float_as_uint(reduce4_max(tb[g].k1)) & kKeepRow);
+            const float top_d = __uint_as_float(__float_as_uint(reduce4_max(td[g].k1)) & kKeepRow);
+            const float lbm = reduce4_max(lbmax[g]);
+            const bool bad = odd[g] || (hasp && reduce4_add(oddp[g] ? 1u : 0u) != 0u);
             float t = top_b - Eb[g];
             if (has0) t = fmaxf(t, top_d - Eb[g]);
-            if (hasp) t = fmaxf(t, lbmax[g]);
-            T[g] = t;
-            thr_b[g] = t - Eb[g];
+            if (hasp) t = fmaxf(t, lbm);
+            T[g] = bad ? -__builtin_inff() : t;                     // every row survives: the exhaustive evaluation takes over
+            thr_b[g] = (T[g] - Eb[g]) * (1.0f - 0x1p-15f);          // for MFMA rows, on keys or values
+            const float thr_p = T[g] * (1.0f - 0x1p-13f);           // for the pairs' upper-bound keys
             const bool live = tc[g].live && nz[g];                 // an all-zero residual projects to 0 everywhere: index -1
-            const bool unclear_b = !(second_b < thr_b[g]) || (has0 && !(second_d < thr_b[g])) || !(thr_b[g] > 0.0f) || odd_b ||
-                                   (has0 && odd_d) || (hasp && odd_p);
-            const bool unclear_p = hasp && (!(second_p < t) || odd_p || !(t > 0.0f) || odd_b || (has0 && odd_d));
+            const bool vague = bad || !(thr_b[g] > 0.0f);           // zero pads and everything else would qualify
+            const bool unclear_b = vague || !(tb[g].k2 < thr_b[g]) || (has0 && !(td[g].k2 < thr_b[g]));
+            const bool unclear_p = hasp && (vague || !(tp[g].k2 < thr_p));
             pass2[g] = __ballot(live && unclear_b) != 0;
-            rescan[g] = live && unclear_p;
+            rescan[g] = live && reduce4_add(unclear_p ? 1u : 0u) != 0u;
             if (live && !pass2[g]) {
-                if (mine_b && !(top_b < thr_b[g])) sv[g].push(tb[g].row);
-                if (has0 && mine_d && !(top_d < thr_b[g])) sv[g].push((1 << 16) | td[g].row);
+                if (!(tb[g].k1 < thr_b[g])) {
+                    const unsigned code = __float_as_uint(tb[g].k1) & 127u;
+                    sv[g].push((int)(16 * (code >> 2) + 4 * h + (code & 3u)));
+                }
+                if (has0 && !(td[g].k1 < thr_b[g])) {
+                    const unsigned code = __float_as_uint(td[g].k1) & 127u;
+                    sv[g].push((1 << 16) | (int)(16 * (code >> 2) + 4 * h + (code & 3u)));
+                }
             }
-            if (live && hasp && !unclear_p && mine_p && !(top_p < t)) sv[g].push((2 << 16) | tp[g].row);
+            if (live && hasp && !rescan[g] && !(tp[g].k1 < thr_p)) {
+                const unsigned code = __float_as_uint(tp[g].k1) & 511u;
+                sv[g].push((2 << 16) | (int)((code >> 4) << 11) | (int)(16 * ((code >> 2) & 3u) + 4 * h + (code & 3u)));
+            }
         });
+        STAMP(5)
 
         // ---- (6) pass 2 for groups with an unclear tile-channel: the same MFMAs again, every row at or above the threshold
         bool any2 = false;
 #pragma unroll
         for (int g = 0; g < kGroups; ++g) any2 = any2 || pass2[g];
         if (any2) {
+            static_for<kGroups>([&](auto gc) { COUNT(13, pass2[decltype(gc)::value] ? 1 : 0) });
             uint4 cur[4], nxt[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) cur[q] = s_tiles[q * 64 + lane];
+            lds_tile(cur, 0);
             const int last = any0 ? kTilesLds : kBaseFilterTiles;
+#pragma unroll 1
             for (int t = 0; t < last; ++t) {
-                const int tn = t + 1 < last ? t + 1 : t;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) nxt[q] = s_tiles[tn * 256 + q * 64 + lane];
+                lds_tile(nxt, t + 1 < last ? t + 1 : t);
                 const bool is_base = t < kBaseFilterTiles;
                 const int row0 = (is_base ? t : t - kBaseFilterTiles) * 16 + 4 * h;
                 const int limit = is_base ? a.num_base : a.rows0;
                 static_for<kGroups>([&](auto gc) {
                     constexpr int g = decltype(gc)::value;
-                    if (!pass2[g] || (!is_base && !want0[g])) return;
+                    if (!pass2[g]) return;
                     const f32x4 acc = tile_mfma(cur, bh[g], bl[g]);
                     const bool wanted = tc[g].live && nz[g] && (is_base || tc[g].has0);
 #pragma unroll
@@ -461,6 +643,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void mp_pursuit_kernel(const Pursui
                 for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
             }
         }
+        STAMP(6)
         // pairs of an unclear tile-channel: every row whose upper bound reaches T
         static_for<kGroups>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
@@ -483,24 +666,22 @@ __global__ __launch_bounds__(64 * kWaves, 2) void mp_pursuit_kernel(const Pursui
                 }
             }
         });
+        STAMP(7)
 
-        // ---- (7) exact evaluation of the survivors, one per tile-channel and round, by the four lanes of its slot ----------
+        // ---- (7) exact evaluation of the survivors, one per tile-channel and round, by the four lanes of its slot; both groups'
+        //      rows are in flight together and their two sums run side by side
         double best_val[kGroups];
         int best_idx[kGroups], best_sel[kGroups];
-        const double* best_ptr[kGroups];
         int c0[kGroups], c1[kGroups], c2[kGroups], total[kGroups];
         bool exhaustive[kGroups];
 #pragma unroll
         for (int g = 0; g < kGroups; ++g) {
-            best_val[g] = 0.0; best_idx[g] = -1; best_sel[g] = 0; best_ptr[g] = a.base;
+            best_val[g] = 0.0; best_idx[g] = -1; best_sel[g] = 0;
             c0[g] = __shfl(sv[g].count, slot);
             c1[g] = __shfl(sv[g].count, slot + 16);
             c2[g] = __shfl(sv[g].count, slot + 32);
             total[g] = c0[g] + c1[g] + c2[g] + __shfl(sv[g].count, slot + 48);
-            int o = sv[g].overflow ? 1 : 0;
-            o |= __shfl_xor(o, 16);
-            o |= __shfl_xor(o, 32);
-            exhaustive[g] = o != 0;
+            exhaustive[g] = reduce4_add(sv[g].overflow ? 1u : 0u) != 0u;
         }
         // what a code means for this lane's tile-channel: the row's address, its dictionary index and its Gram row
         auto resolve = [&](auto gc, int code, const double*& ptr, int& idx, int& sel) {
@@ -512,65 +693,98 @@ __global__ __launch_bounds__(64 * kWaves, 2) void mp_pursuit_kernel(const Pursui
                 const int p = (code >> 11) & 31;
                 const long long pi = (long long)(g * 16 + slot) * kMaxPairs + p;
                 const unsigned meta = my_meta[2 * pi];
-                const int drow = (int)my_meta[2 * pi + 1] + row;
+                const int drow = s_rowoff[meta & 511u] + row;
                 ptr = a.detail + (long long)drow * N;
                 idx = (int)(meta >> 16) + row;
                 sel = a.num_base + drow;
             }
         };
-        auto evaluate = [&](auto gc, bool on, int code) {
-            constexpr int g = decltype(gc)::value;
-            const double* ptr = a.base;
-            int idx = -1, sel = 0;
-            if (on) resolve(gc, code, ptr, idx, sel);
-            double x[16];
-            load16(x, ptr + 16 * h);
+        auto evaluate2 = [&](const bool (&on)[kGroups], const int (&code)[kGroups]) {
+            const double* ptr[kGroups];
+            int idx[kGroups], sel[kGroups];
+            double x[kGroups][16];
+            static_for<kGroups>([&](auto gc) {
+                constexpr int g = decltype(gc)::value;
+                ptr[g] = a.base; idx[g] = -1; sel[g] = 0;
+                if (on[g]) resolve(gc, code[g], ptr[g], idx[g], sel[g]);
+            });
 #pragma unroll
-            for (int i = 0; i < 16; ++i) x[i] = x[i] * r[g][i];             // the reference's l * r, rounded to double
-            const double p = chain_sum(x, lane);
-            if (on) keep_better(best_val[g], best_idx[g], best_sel[g], best_ptr[g], p, idx, sel, ptr);
+            for (int g = 0; g < kGroups; ++g) load16(x[g], ptr[g] + pix0);
+#pragma unroll
+            for (int g = 0; g < kGroups; ++g)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) x[g][i] = x[g][i] * r[g][i];          // the reference's l * r, rounded to double
+            double p[kGroups];
+#pragma unroll
+            for (int g = 0; g < kGroups; ++g) p[g] = chain_sum(x[g], h);
+#pragma unroll
+            for (int g = 0; g < kGroups; ++g)
+                if (on[g]) keep_better(best_val[g], best_idx[g], best_sel[g], p[g], idx[g], sel[g]);
         };
         for (int k = 0;; ++k) {
             bool on[kGroups];
+            int code[kGroups];
             bool any = false;
 #pragma unroll
             for (int g = 0; g < kGroups; ++g) {
                 on[g] = unit[g] >= 0 && tc[g].live && !exhaustive[g] && k < total[g];
                 any = any || on[g];
-            }
-            if (!__ballot(any)) break;
-            static_for<kGroups>([&](auto gc) {
-                constexpr int g = decltype(gc)::value;
-                if (!__ballot(on[g])) return;
                 const int owner = k < c0[g] ? 0 : (k < c0[g] + c1[g] ? 1 : (k < c0[g] + c1[g] + c2[g] ? 2 : 3));
                 const int local = k - (owner == 0 ? 0 : (owner == 1 ? c0[g] : (owner == 2 ? c0[g] + c1[g] : c0[g] + c1[g] + c2[g])));
-                const int code = __shfl(sv[g].at(local & 3), slot + 16 * owner);
-                evaluate(gc, on[g], code);
-            });
-        }
-        // a tile-channel whose survivors did not fit (many exact ties, NaN): every row it can choose from, in order
-        static_for<kGroups>([&](auto gc) {
-            constexpr int g = decltype(gc)::value;
-            if (unit[g] < 0) return;
-            const bool ex = tc[g].live && nz[g] && exhaustive[g];
-            if (!__ballot(ex)) return;
-            const int n_all = a.num_base + 64 + 64 * tc[g].npairs;
-            for (int n = 0; __ballot(ex && n < n_all) != 0; ++n) {
-                bool on = ex && n < n_all;
-                int code = 0;
-                if (n < a.num_base) code = n;
-                else if (n < a.num_base + 64) { code = (1 << 16) | (n - a.num_base); on = on && tc[g].has0 && n - a.num_base < a.rows0; }
-                else {
-                    const int p = (n - a.num_base - 64) >> 6, row = (n - a.num_base - 64) & 63;
-                    code = (2 << 16) | (p << 11) | row;
-                    if (on) on = row < (int)((my_meta[2 * ((long long)(g * 16 + slot) * kMaxPairs + p)] >> 9) & 127u);
-                }
-                if (!__ballot(on)) continue;
-                evaluate(gc, on, code);
+                code[g] = __shfl(sv[g].at(local & 3), slot + 16 * owner);
             }
-        });
+            if (!__ballot(any)) break;
+            COUNT(14, 1)
+            evaluate2(on, code);
+        }
+        STAMP(8)
+        // a tile-channel whose survivors did not fit (many exact ties, NaN): every row it can choose from, in order
+        {
+            bool ex[kGroups];
+            int n_all[kGroups];
+            bool any_ex = false;
+#pragma unroll
+            for (int g = 0; g < kGroups; ++g) {
+                ex[g] = unit[g] >= 0 && tc[g].live && nz[g] && exhaustive[g];
+                n_all[g] = a.num_base + 64 + 64 * tc[g].npairs;
+                any_ex = any_ex || ex[g];
+            }
+            if (__ballot(any_ex)) {
+                COUNT(15, 1)
+                for (int n = 0;; ++n) {
+                    bool on[kGroups];
+                    int code[kGroups];
+                    bool more = false, any = false;
+                    static_for<kGroups>([&](auto gc) {
+                        constexpr int g = decltype(gc)::value;
+                        on[g] = ex[g] && n < n_all[g];
+                        more = more || on[g];
+                        code[g] = 0;
+                        if (n < a.num_base) code[g] = n;
+                        else if (n < a.num_base + 64) { code[g] = (1 << 16) | (n - a.num_base); on[g] = on[g] && tc[g].has0 && n - a.num_base < a.rows0; }
+                        else {
+                            const int p = (n - a.num_base - 64) >> 6, row = (n - a.num_base - 64) & 63;
+                            code[g] = (2 << 16) | (p << 11) | row;
+                            if (on[g]) on[g] = row < (int)((my_meta[2 * ((long long)(g * 16 + slot) * kMaxPairs + p)] >> 9) & 127u);
+                        }
+                        any = any || on[g];
+                    });
+                    if (!__ballot(more)) break;
+                    if (!__ballot(any)) continue;
+                    evaluate2(on, code);
+                }
+            }
+        }
+        STAMP(9)
 
-        // ---- (8) finish: delta / zig-zag, quantise, record, unlock, termination (MatchingPursuit.cpp:50-71) ------------------
+        // ---- (8) finish.  The chosen rows are requested first (the residual update needs them), then everything that stores.
+        double xrow[kGroups][16];
+#pragma unroll
+        for (int g = 0; g < kGroups; ++g) {
+            const int sg = (unit[g] >= 0 && tc[g].live && best_idx[g] >= 0) ? best_sel[g] : 0;      // Gram row -> the row itself
+            load16(xrow[g], (sg < a.num_base ? a.base + (long long)sg * N : a.detail + (long long)(sg - a.num_base) * N) + pix0);
+        }
+        // delta / zig-zag, quantise, record, unlock, termination (MatchingPursuit.cpp:50-71)
         bool ended[kGroups];
         static_for<kGroups>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
@@ -598,23 +812,23 @@ __global__ __launch_bounds__(64 * kWaves, 2) void mp_pursuit_kernel(const Pursui
                 } else {
                     s.coeff = qstep * (double)q;
                     s.sel_g = best_sel[g];
-                    s.sel_row = best_ptr[g];
                     if (step[g] + 1 == K) { ended[g] = true; count = K; }
                     else if (id < a.num_base) {                     // unlock DetailBasis[id]; a repeat is indexed, not swept again
-                        const int rows = a.block_rows[id];
+                        const int rows = s_rows[id];
                         bool repeat = id == 0 && s.has0;
-                        for (int p = 0; p < s.npairs; ++p)
-                            repeat = repeat || (int)(my_meta[2 * ((long long)(g * 16 + slot) * kMaxPairs + p)] & 511u) == id;
+                        for (int p = 0; p < s.npairs; ++p) {
+                            const unsigned blk = p < 4 ? (s.packed(p) & 511u) : (my_meta[2 * ((long long)(g * 16 + slot) * kMaxPairs + p)] & 511u);
+                            repeat = repeat || (int)blk == id;
+                        }
                         if (!repeat) {
                             if (id == 0) { s.has0 = true; s.off0 = s.next_off; }
                             else {
                                 const long long pi = (long long)(g * 16 + slot) * kMaxPairs + s.npairs;
-                                if (h == 0) {
-                                    my_meta[2 * pi] = (unsigned)id | ((unsigned)rows << 9) | ((unsigned)s.next_off << 16);
-                                    my_meta[2 * pi + 1] = (unsigned)a.block_row_off[id];
-                                }
+                                const unsigned info = (unsigned)id | ((unsigned)rows << 9);
+                                if (h == 0) my_meta[2 * pi] = info | ((unsigned)s.next_off << 16);
+                                if (s.npairs < 2) s.pk0 |= info << (16 * s.npairs);
+                                else if (s.npairs < 4) s.pk1 |= info << (16 * (s.npairs - 2));
                                 s.fresh = s.npairs;
-                                s.fresh_blk = id;
                                 s.npairs += 1;
                             }
                         }
@@ -623,45 +837,65 @@ __global__ __launch_bounds__(64 * kWaves, 2) void mp_pursuit_kernel(const Pursui
                 }
             }
             if (h == 0) {
-                a.out.choices[(long long)s.rec * K + step[g]] = record;
+                const long long rec = rec_of(unit[g]);
+                a.out.choices[rec * K + step[g]] = record;
                 if (ended[g]) {
-                    a.out.counts[s.rec] = (uint16_t)count;
-                    if (a.out.swept) a.out.swept[s.rec] = s.swept;
+                    a.out.counts[rec] = (uint16_t)count;
+                    if (a.out.swept) a.out.swept[rec] = s.swept;
                 }
             }
         });
-        // the lanes of a slot wrote the pair's meta words from h == 0 only: make them visible to the other three before use
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        STAMP(10)
 
-        // ---- (9) residual update r -= (q * quant) * row: Vector::Scale then Vector::Subtract, two roundings --------------------
+        // ---- (9) residual update r -= (q * quant) * row: Vector::Scale then Vector::Subtract, two roundings.  Behind it, what
+        //      the next step will read from far away is pulled towards the cache by LDS-DMA into a landing zone nobody reads (no
+        //      register, no wait): the Gram rows of the pairs, the filter tiles of a new pair.
         static_for<kGroups>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
             if (unit[g] < 0) return;
             TileChannel& s = tc[g];
-            if (__ballot(s.live && s.coeff != 0.0)) {
-                double x[16];
-                load16(x, (s.live && s.coeff != 0.0 ? s.sel_row : a.base) + 16 * h);
-                if (s.live && s.coeff != 0.0) {
+            const bool upd = s.live && s.coeff != 0.0;
+            if (upd) {
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const double scaled = s.coeff * x[i];
-                        r[g][i] = r[g][i] - scaled;
-                    }
+                for (int i = 0; i < 16; ++i) {
+                    const double scaled = s.coeff * xrow[g][i];
+                    r[g][i] = r[g][i] - scaled;
                 }
             }
             if (a.out.energy && __ballot(s.live && ended[g])) {    // diagnostic: sum of squares of the final residual, j ascending
                 double sq[16];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) sq[i] = r[g][i] * r[g][i];
-                const double e2 = chain_sum(sq, lane);
-                if (s.live && ended[g] && h == 0) a.out.energy[s.rec] = e2;
+                const double e2 = chain_sum(sq, h);
+                if (s.live && ended[g] && h == 0) a.out.energy[rec_of(unit[g])] = e2;
+            }
+            if (upd && !ended[g] && h < 2) {
+                const int np = s.npairs < 4 ? s.npairs : 4;
+                for (int p = 0; p < np; ++p) {
+                    if (p == s.fresh) continue;
+                    const float* line = a.gram + (long long)s.sel_g * a.gram_stride + (int)(s.packed(p) & 511u) * 64 + 32 * h;
+                    __builtin_amdgcn_global_load_lds(line, my_touch, 4, 0, 0);
+                }
+            }
+            unsigned long long pend = __ballot(s.live && !ended[g] && s.fresh >= 0 && s.fresh < 4 && h == 0);
+            while (pend) {                                          // a new pair's 16 KiB of filter tiles: 128 lines, two per lane
+                const int src = __builtin_ctzll(pend);
+                pend &= pend - 1;
+                const int blk = __builtin_amdgcn_readlane((int)(s.packed(s.fresh < 4 ? s.fresh : 0) & 511u), src);
+                const uint16_t* tiles = a.block_tiles + (long long)blk * (kBlockFilterTiles * 2048) + 64 * lane;
+                __builtin_amdgcn_global_load_lds(tiles, my_touch, 4, 0, 0);
+                __builtin_amdgcn_global_load_lds(tiles + 4096, my_touch, 4, 0, 0);
             }
             if (ended[g]) s.live = false;
             step[g] += 1;
             if (!__ballot(s.live)) unit[g] = -1;
         });
+        STAMP(11)
     }
+#ifdef MPC_STAMPS
+    if (lane == 0 && a.debug)
+        for (int i = 0; i < 24; ++i) atomicAdd(a.debug + i, stamp_acc[i]);
+#endif
 }
 
 // --------------------------------------------------------------------------------------------------

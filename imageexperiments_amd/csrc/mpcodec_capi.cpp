@@ -349,6 +349,10 @@ mpc_status run_persistent(mpc_context* c, const mpc::FrameInput& in, const mpc::
     if (n_units >= (1LL << 31)) return fail(MPC_ERR_ARGUMENT, "batch too large");
     const int per_wg = mpc::pursuit_units_per_workgroup();
     int workgroups = static_cast<int>(std::min<long long>((n_units + per_wg - 1) / per_wg, d.workgroups));
+    // One workgroup fits a CU (its LDS holds the dictionary), and the three channel launches run side by side.  A small frame
+    // (less than three rounds of the machine in all) gets a third of the CUs per channel, so that no channel waits for CUs
+    // another one holds; a large one is dominated by the luma launch, which then wants every CU.
+    if (!vec && 3 * n_units < 3LL * d.workgroups * per_wg) workgroups = std::min(workgroups, std::max(1, d.workgroups / 3));
     const int forced = env_int("MPC_WORKGROUPS", 0);
     if (forced > 0) workgroups = std::min(forced, d.workgroups);
     std::lock_guard<std::mutex> hold(d.launch_lock);
@@ -401,8 +405,27 @@ mpc_status run_persistent(mpc_context* c, const mpc::FrameInput& in, const mpc::
             c->timing_used = need;
             HIP_TRY(hipEventRecord(ev[0], s));
         }
+#ifdef MPC_STAMPS
+        static unsigned long long* d_debug = nullptr;
+        if (!d_debug) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_debug), 24 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemsetAsync(d_debug, 0, 24 * sizeof(unsigned long long), s));
+        a.debug = d_debug;
+#endif
         const int err = mpc::launch_pursuit(a, workgroups, s);
         if (err != 0) return fail(MPC_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(err)));
+#ifdef MPC_STAMPS
+        {
+            unsigned long long hst[24];
+            HIP_TRY(hipStreamSynchronize(s));
+            HIP_TRY(hipMemcpy(hst, d_debug, sizeof hst, hipMemcpyDeviceToHost));
+            unsigned long long tot = 0;
+            for (int i = 0; i < 12; ++i) tot += hst[i];
+            std::fprintf(stderr, "[stamps ch%d wg%d] wave-steps %llu live-lanes/step %.1f pass2-groups %llu rounds %llu exhaustive %llu | cycles/wave-step:",
+                         ch, workgroups, hst[12], hst[12] ? (double)hst[16] / hst[12] / 4.0 : 0.0, hst[13], hst[14], hst[15]);
+            for (int i = 0; i < 12; ++i) std::fprintf(stderr, " %d:%.0f", i, hst[12] ? (double)hst[i] / hst[12] : 0.0);
+            std::fprintf(stderr, " total %.0f\n", hst[12] ? (double)tot / hst[12] : 0.0);
+        }
+#endif
         if (ev) HIP_TRY(hipEventRecord(ev[1], s));
         HIP_TRY(hipEventRecord(d.done[ch], s));
         HIP_TRY(hipStreamWaitEvent(caller, d.done[ch], 0));
