@@ -101,6 +101,8 @@ def _bind_bitstream(L):
     L.mpc_rle_decode.argtypes = [_u16p, C.c_size_t, C.POINTER(_u16p), C.POINTER(C.c_size_t)]
     L.mpc_encode_image.argtypes = [vp, _u8p, C.c_int, C.c_int, _dp, C.POINTER(_u8p), C.POINTER(C.c_size_t)]
     L.mpc_encode_images.argtypes = [vp, C.POINTER(_u8p), C.c_int, C.c_int, C.c_int, _dp, C.POINTER(_u8p), C.POINTER(C.c_size_t)]
+    L.mpc_encode_images_device.argtypes = [vp, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, _dp, C.POINTER(_u8p), C.POINTER(C.c_size_t)]
+    L.mpc_encode_image_device.argtypes = [vp, vp, C.c_int, C.c_int, _dp, C.POINTER(_u8p), C.POINTER(C.c_size_t)]
     L.mpc_decode_tiles_device.argtypes = [vp, vp, vp, _dp, C.c_int, C.c_int, vp, vp]
     L.mpc_decode_image.argtypes = [vp, _u8p, C.c_size_t, C.POINTER(_u8p), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.mpc_patch_stats_create.argtypes = [vp, C.c_uint, C.POINTER(vp)]
@@ -446,6 +448,23 @@ class CompressionContext:
         sizes = (C.c_size_t * n)()
         _check(self.L.mpc_encode_images(self.h, ptrs, n, W, H, qp, outs, sizes))
         return [_take_bytes(self.L, outs[i], C.c_size_t(sizes[i])) for i in range(n)]
+
+    def encode_images_device(self, d_frames, width, height, quant=None):
+        """mpc_encode_images_device: frames already in device memory (ints from tensor.data_ptr(), tightly packed RGB).
+        Returns a list of bytes objects (containers), pipelined like encode_images."""
+        qp = None
+        if quant is not None:
+            quant = np.ascontiguousarray(quant, np.float64).reshape(3, self.K)
+            qp = quant.ctypes.data_as(_dp)
+        n = len(d_frames)
+        ptrs = (C.c_void_p * n)(*[C.c_void_p(int(p)) for p in d_frames])
+        outs = (_u8p * n)()
+        sizes = (C.c_size_t * n)()
+        _check(self.L.mpc_encode_images_device(self.h, ptrs, n, width, height, qp, outs, sizes))
+        return [_take_bytes(self.L, outs[i], C.c_size_t(sizes[i])) for i in range(n)]
+
+    def encode_image_device(self, d_rgb, width, height, quant=None):
+        return self.encode_images_device([d_rgb], width, height, quant)[0]
 
     def calc_mp(self, channel, vectors, quant_k=None):
         """matching::CalcMPDynamic (MatchingPursuit.h:22) on the device for vectors[n,64].

@@ -914,6 +914,48 @@ uint8_t* encode_records_malloc(int width, int height, int K, int block_size, con
     return concat_malloc(head, parts, nbytes);
 }
 
+// The container from streams the device has already assembled (mp_streams.hip): `symbols` holds codes[0], codes[1], ... codes[6K-1]
+// back to back (stream s = symbols[off[s] .. off[s+1])), live symbols only, in the reference's tile order, the three step-0
+// coefficient streams already difference coded.  One job per stream (the lengths stream first: the longest).
+uint8_t* encode_symbol_streams_malloc(int width, int height, int K, int block_size, const double* quant, const uint16_t* counts,
+                                      const uint16_t* symbols, const unsigned long long* off, size_t* nbytes) {
+    const size_t tiles = static_cast<size_t>((width + block_size - 1) / block_size) *
+                         static_cast<size_t>((height + block_size - 1) / block_size);
+    BitWriter head;
+    head.put(kMagic, 32);
+    head.put(static_cast<uint32_t>(width), 32);
+    head.put(static_cast<uint32_t>(height), 32);
+    head.put(static_cast<uint8_t>(K), 8);
+    head.put(static_cast<uint8_t>(block_size), 8);
+    for (int ch = 0; ch < 3; ++ch)
+        for (int i = 0; i < K; ++i) head.put(static_cast<uint16_t>(quant[ch * K + i]), 16);    // :420 u16 of an integral double
+    std::vector<BitWriter> parts(static_cast<size_t>(6 * K + 1));
+    // longest jobs first: the lengths stream, then the streams in the order of their sizes
+    std::vector<int> order(static_cast<size_t>(6 * K));
+    for (int s = 0; s < 6 * K; ++s) order[static_cast<size_t>(s)] = s;
+    std::sort(order.begin(), order.end(), [&](int x, int y) { return off[x + 1] - off[x] > off[y + 1] - off[y]; });
+    parallel_for(6 * K + 1, [&](int job) {
+        if (job == 0) {
+            write_huffman_or_golomb(counts, 3 * tiles, parts[0]);
+            return;
+        }
+        const int s = order[static_cast<size_t>(job - 1)];
+        const uint16_t* data = symbols + off[s];
+        const size_t n = static_cast<size_t>(off[s + 1] - off[s]);
+        BitWriter& w = parts[static_cast<size_t>(s + 1)];
+        const std::vector<uint16_t> packed = rle_encode(data, n);
+        if (packed.size() + 4 < n) {                              // CompressedImage.cpp:450
+            w.put(1, 1);
+            w.put(static_cast<uint32_t>(packed.size()), 32);
+            write_huffman_or_golomb(packed.data(), packed.size(), w);
+        } else {
+            w.put(0, 1);
+            write_huffman_or_golomb(data, n, w);
+        }
+    });
+    return concat_malloc(head, parts, nbytes);
+}
+
 uint8_t* encode_planar_records_malloc(int width, int height, int K, int block_size, const double* quant, const uint16_t* counts,
                                       const uint32_t* planar, size_t* nbytes) {
     const size_t tiles = static_cast<size_t>((width + block_size - 1) / block_size) *

@@ -86,6 +86,11 @@ uint8_t* encode_records_malloc(int width, int height, int K, int block_size, con
 uint8_t* encode_planar_records_malloc(int width, int height, int K, int block_size, const double* quant, const uint16_t* counts,
                                       const uint32_t* planar, size_t* nbytes);
 
+// same container from streams assembled on the device (mp_streams.hip): symbols = codes[0] ++ codes[1] ++ ... (live symbols
+// only, step-0 coefficients already difference coded), off[6K + 1] = stream boundaries in symbols
+uint8_t* encode_symbol_streams_malloc(int width, int height, int K, int block_size, const double* quant, const uint16_t* counts,
+                                      const uint16_t* symbols, const unsigned long long* off, size_t* nbytes);
+
 // Inverse of assemble_streams: per-tile records in the reference's visiting order.  counts[3*tiles],
 // choices[3*tiles*K] (deltaId | intCoeff << 16, zero beyond count).  false = streams inconsistent with `lengths`.
 bool disassemble_streams(const Streams& s, std::vector<uint16_t>& counts, std::vector<uint32_t>& choices);

@@ -173,6 +173,21 @@ int pursuit_units_per_workgroup();
 int launch_gram(const double* base, const double* detail, const int32_t* block_rows, const int32_t* block_row_off,
                 const uint8_t* shadow, float* gram, int num_base, int n_sel, long long stride, void* stream);
 
+// ---- device-side stream assembly (mp_streams.hip) ----
+struct StreamArgs {
+    const uint16_t* counts;          // [tiles][3]
+    const uint32_t* choices;         // [tiles][3][K]
+    long long tiles;
+    int K;
+    unsigned* block_live;            // [stream_workspace_words(tiles, K)] scratch
+    unsigned* sizes;                 // [3][K] out: symbols per (channel, step)
+    unsigned long long* stream_off;  // [6K + 1] out: stream boundaries in `symbols` (container order)
+    uint16_t* symbols;               // [2 * 3 * K * tiles] worst case; out: the 6K streams back to back
+    uint16_t* dc_tmp;                // [3][tiles] scratch
+};
+size_t stream_workspace_words(long long tiles, int K);
+int launch_stream_assembly(const StreamArgs& a, void* stream);
+
 // choices[tiles][3][K] -> planar[3][K][tiles] (what the host entropy stage of mpc_encode_image(s) reads); hipError_t as int
 int launch_planar_records(const uint32_t* choices, uint32_t* planar, long long tiles, int K, void* stream);
 

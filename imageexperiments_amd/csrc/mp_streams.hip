@@ -1,0 +1,163 @@
+// mp_streams.hip -- product: device-side stream assembly for the MI355X tile encoder.
+//
+// The container holds, besides `lengths`, 6K symbol streams: codes[2K*ch + 2i] = deltaId and [+1] = intCoeff of step i of
+// channel ch for every tile with more than i atoms, tiles in the reference's visiting order (x outer, y inner:
+// CompressedImage.cpp:535-572); the three step-0 coefficient streams are difference coded (:428-446).  The pursuit leaves
+// records [tile][3][K] of which most are dead (97 MB for a 16 Mpixel K = 32 frame, 21 MB alive).  These kernels compact the
+// live symbols stream by stream, in stream order, into ONE contiguous u16 buffer laid out in container order and apply the
+// DC differencing, so that only the live symbols cross PCIe and every host coding job starts from a finished stream:
+//   count    per block of 1024 tiles and channel: tiles with more than i atoms, for every i (from a histogram of the counts)
+//   scan     exclusive scan of those over the blocks (one thread per stream pair); stream sizes and offsets
+//   scatter  rank of every live symbol inside its block by ballots, write deltaId / intCoeff to their stream positions
+//   dc       zig-zag difference of the three step-0 coefficient streams (CompressedImage.cpp:428-446)
+// HBM-bound byte shuffling: reads are 16-byte vectors of whole records, writes are runs of consecutive u16.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mp_device.h"
+
+namespace mpc {
+
+namespace {
+constexpr int kBlockTiles = 1024;               // tiles per workgroup (thread = tile)
+constexpr int kWavesPerBlock = kBlockTiles / 64;
+}  // namespace
+
+__global__ __launch_bounds__(kBlockTiles) void mp_stream_count_kernel(const StreamArgs a)
+{
+    __shared__ unsigned hist[3][kMaxDeviceK + 2];
+    for (int i = threadIdx.x; i < 3 * (kMaxDeviceK + 2); i += kBlockTiles) (&hist[0][0])[i] = 0;
+    __syncthreads();
+    const long long t = (long long)blockIdx.x * kBlockTiles + threadIdx.x;
+    if (t < a.tiles) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const int c = a.counts[t * 3 + ch];
+            atomicAdd(&hist[ch][c < a.K ? c : a.K], 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3 * a.K) {
+        const int ch = threadIdx.x / a.K, i = threadIdx.x - ch * a.K;
+        unsigned live = 0;
+        for (int c = i + 1; c <= a.K; ++c) live += hist[ch][c];
+        a.block_live[((long long)blockIdx.x * 3 + ch) * a.K + i] = live;
+    }
+}
+
+// one thread per (channel, step): exclusive scan over the blocks; thread 0 then lays the streams out in container order
+__global__ __launch_bounds__(128) void mp_stream_scan_kernel(const StreamArgs a, int blocks)
+{
+    __shared__ unsigned total[3 * kMaxDeviceK];
+    if ((int)threadIdx.x < 3 * a.K) {
+        const int ch = threadIdx.x / a.K, i = threadIdx.x - ch * a.K;
+        unsigned run = 0;
+        for (int b = 0; b < blocks; ++b) {
+            const long long at = ((long long)b * 3 + ch) * a.K + i;
+            const unsigned n = a.block_live[at];
+            a.block_live[at] = run;                               // in place: live count -> offset of the block in its stream
+            run += n;
+        }
+        total[threadIdx.x] = run;
+        a.sizes[threadIdx.x] = run;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long off = 0;
+        for (int ch = 0; ch < 3; ++ch)
+            for (int i = 0; i < a.K; ++i) {
+                const unsigned n = total[ch * a.K + i];
+                a.stream_off[2 * (ch * a.K + i)] = off;           // codes[2K*ch + 2i]     deltaId
+                off += n;
+                a.stream_off[2 * (ch * a.K + i) + 1] = off;       // codes[2K*ch + 2i + 1] intCoeff
+                off += n;
+            }
+        a.stream_off[6 * a.K] = off;                              // symbols in all
+    }
+}
+
+__global__ __launch_bounds__(kBlockTiles) void mp_stream_scatter_kernel(const StreamArgs a)
+{
+    __shared__ unsigned wave_live[kWavesPerBlock][kMaxDeviceK];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long t = (long long)blockIdx.x * kBlockTiles + threadIdx.x;
+    const bool in = t < a.tiles;
+    const unsigned long long below = (1ULL << lane) - 1ULL;
+    for (int ch = 0; ch < 3; ++ch) {
+        const int c = in ? (int)a.counts[t * 3 + ch] : 0;
+        uint32_t rec[kMaxDeviceK];
+        {
+            const uint4* src = reinterpret_cast<const uint4*>(a.choices + ((in ? t : 0) * 3 + ch) * a.K);
+#pragma unroll
+            for (int v = 0; v < kMaxDeviceK / 4; ++v) {
+                uint4 x = make_uint4(0, 0, 0, 0);
+                if (4 * v < a.K && (a.K & 3) == 0) x = src[v];
+                rec[4 * v] = x.x; rec[4 * v + 1] = x.y; rec[4 * v + 2] = x.z; rec[4 * v + 3] = x.w;
+            }
+            if ((a.K & 3) != 0) {                                // K not a multiple of 4: records are not 16-byte aligned
+                const uint32_t* s1 = a.choices + ((in ? t : 0) * 3 + ch) * a.K;
+#pragma unroll
+                for (int i = 0; i < kMaxDeviceK; ++i) rec[i] = i < a.K ? s1[i] : 0u;
+            }
+        }
+        __syncthreads();                                          // wave_live of the previous channel is no longer read
+#pragma unroll
+        for (int i = 0; i < kMaxDeviceK; ++i)
+            if (i < a.K) {
+                const unsigned long long live = __ballot(c > i);
+                if (lane == 0) wave_live[wave][i] = (unsigned)__popcll(live);
+            }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < kMaxDeviceK; ++i)
+            if (i < a.K) {
+                const unsigned long long live = __ballot(c > i);
+                if (!live) continue;
+                unsigned before = 0;
+                for (int w = 0; w < wave; ++w) before += wave_live[w][i];
+                if (c > i) {
+                    const unsigned long long pos = (unsigned long long)a.block_live[((long long)blockIdx.x * 3 + ch) * a.K + i] + before +
+                                                   (unsigned)__popcll(live & below);
+                    const unsigned long long od = a.stream_off[2 * (ch * a.K + i)], oc = a.stream_off[2 * (ch * a.K + i) + 1];
+                    a.symbols[od + pos] = (uint16_t)(rec[i] & 0xFFFFu);
+                    // step-0 coefficients go through the difference kernel: parked behind the end of all streams
+                    uint16_t* coeff = i == 0 ? a.dc_tmp + (long long)ch * a.tiles : a.symbols + oc;
+                    coeff[pos] = (uint16_t)(rec[i] >> 16);
+                }
+            }
+    }
+}
+
+__global__ __launch_bounds__(256) void mp_stream_dc_kernel(const StreamArgs a)
+{
+    for (int ch = 0; ch < 3; ++ch) {
+        const unsigned n = a.sizes[ch * a.K];
+        const uint16_t* src = a.dc_tmp + (long long)ch * a.tiles;
+        uint16_t* dst = a.symbols + a.stream_off[2 * (ch * a.K) + 1];
+        for (unsigned long long j = (unsigned long long)blockIdx.x * 256 + threadIdx.x; j < n; j += (unsigned long long)gridDim.x * 256) {
+            const int32_t v = src[j], prev = j ? (int32_t)src[j - 1] : 0;
+            const int32_t d = v - prev;
+            dst[j] = (uint16_t)(((uint32_t)d << 1) ^ (uint32_t)(d >> 31));     // zigzagEncode, BitBuffer.h:116
+        }
+    }
+}
+
+size_t stream_workspace_words(long long tiles, int K)
+{
+    const long long blocks = (tiles + kBlockTiles - 1) / kBlockTiles;
+    return (size_t)(blocks * 3 * K);
+}
+
+int launch_stream_assembly(const StreamArgs& a, void* stream_)
+{
+    hipStream_t s = static_cast<hipStream_t>(stream_);
+    const int blocks = (int)((a.tiles + kBlockTiles - 1) / kBlockTiles);
+    if (blocks < 1 || a.K < 1 || a.K > kMaxDeviceK) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(mp_stream_count_kernel, dim3((unsigned)blocks), dim3(kBlockTiles), 0, s, a);
+    hipLaunchKernelGGL(mp_stream_scan_kernel, dim3(1), dim3(128), 0, s, a, blocks);
+    hipLaunchKernelGGL(mp_stream_scatter_kernel, dim3((unsigned)blocks), dim3(kBlockTiles), 0, s, a);
+    hipLaunchKernelGGL(mp_stream_dc_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, s, a);
+    return (int)hipGetLastError();
+}
+
+}  // namespace mpc

@@ -209,10 +209,11 @@ struct mpc_context {
     void* host_stage = nullptr;       // pinned: records of mpc_encode_image on their way to the entropy stage
     size_t host_stage_bytes = 0;
     // mpc_encode_images: upload / compute / download streams and per-slot events (upload done, pursuit done, download done)
-    hipStream_t seq_up = nullptr, seq_compute = nullptr, seq_down = nullptr;
+    hipStream_t seq_up = nullptr, seq_compute = nullptr;
     static constexpr int kSeqSlots = 4;              // frames in flight in mpc_encode_images
     int pipes_cap = 0;                               // > 0: at most this many concurrent sub-batches per call
     hipEvent_t seq_events[kSeqSlots][3] = {};
+    hipStream_t seq_down[kSeqSlots] = {};             // one download stream per slot: its worker thread drives it
     // The pursuit of a call is cut into sub-batches that run on `pipes` internal streams, each with its own
     // workspace: the latency-bound bookkeeping kernels of one sub-batch (finish, update, bucket, fill) overlap
     // the machine-filling sweeps of the other.  Fork/join with events on the caller's stream: still no host
@@ -551,7 +552,8 @@ void mpc_context_destroy(mpc_context* c) {
         if (c->host_stage) (void)hipHostFree(c->host_stage);
         if (c->seq_up) (void)hipStreamDestroy(c->seq_up);
         if (c->seq_compute) (void)hipStreamDestroy(c->seq_compute);
-        if (c->seq_down) (void)hipStreamDestroy(c->seq_down);
+        for (hipStream_t sd : c->seq_down)
+            if (sd) (void)hipStreamDestroy(sd);
         for (auto& slot : c->seq_events)
             for (hipEvent_t e : slot)
                 if (e) (void)hipEventDestroy(e);
@@ -999,96 +1001,60 @@ mpc_status mpc_rle_decode(const uint16_t* data, size_t n, uint16_t** out, size_t
     });
 }
 
-// compressed::encodeImage: device tile encode + host entropy stage
-mpc_status mpc_encode_image(mpc_context* c, const uint8_t* rgb, int width, int height, const double* quant,
-                            uint8_t** bytes, size_t* nbytes) {
-    return guarded([&]() -> mpc_status {
-    if (!c || !rgb || !bytes || !nbytes) return fail(MPC_ERR_ARGUMENT, "null argument");
-    if (c->device < 0) return fail(MPC_ERR_NO_DEVICE, "context was created without a device; there is no CPU fallback");
-    const int tiles_x = (width + 7) / 8, tiles_y = (height + 7) / 8;
-    const size_t tiles = static_cast<size_t>(tiles_x) * tiles_y;
-    std::lock_guard<std::recursive_mutex> one_host_call(c->host_calls);
-    // the records come back into pinned host memory kept by the context (a fresh 100 MB vector per call costs more in
-    // page faults than the device spends encoding)
-    HIP_TRY(hipSetDevice(c->device));
-    const size_t counts_bytes = (sizeof(uint16_t) * tiles * 3 + 255) & ~static_cast<size_t>(255);
-    const size_t need = counts_bytes + sizeof(mpc_basis_choice) * tiles * 3 * c->K;
-    if (need > c->host_stage_bytes) {
-        if (c->host_stage) (void)hipHostFree(c->host_stage);
-        c->host_stage = nullptr;
-        c->host_stage_bytes = 0;
-        const hipError_t e = hipHostMalloc(&c->host_stage, need, hipHostMallocDefault);
-        if (e != hipSuccess) return fail(MPC_ERR_ALLOC, "pinned staging of %zu bytes: %s", need, hipGetErrorString(e));
-        c->host_stage_bytes = need;
-    }
-    uint16_t* counts = static_cast<uint16_t*>(c->host_stage);
-    mpc_basis_choice* choices = reinterpret_cast<mpc_basis_choice*>(static_cast<char*>(c->host_stage) + counts_bytes);
-    // the records are transposed on the device ([3][K][tiles]) so that every stream of the container is one contiguous
-    // run of the download for the entropy stage
-    mpc_status st = encode_tiles_staged(c, rgb, width, height, static_cast<size_t>(3) * width, 0, tiles_y, quant, counts, choices,
-                                        nullptr, nullptr, true);
-    if (st != MPC_OK) return st;
-    return mpc_assemble_planar_streams(width, height, c->K, c->block_size, quant ? quant : c->quant.data(), counts, choices, bytes,
-                                       nbytes);
-    });
-}
-
-mpc_status mpc_encode_images(mpc_context* c, const uint8_t* const* rgb_frames, int n_frames, int width, int height,
-                             const double* quant, uint8_t** bytes, size_t* nbytes) {
-    return guarded([&]() -> mpc_status {
-    if (!c || !rgb_frames || !bytes || !nbytes || n_frames < 1) return fail(MPC_ERR_ARGUMENT, "bad argument");
+// compressed::encodeImage for a sequence of equally sized frames: device tile encode, device stream assembly (only the live
+// symbols cross PCIe, stream by stream), host entropy stage -- pipelined over kSeqSlots slots.  Frames come from host memory
+// (uploaded through the slot's pinned image on an upload stream) or are already resident on the device.
+static mpc_status encode_sequence(mpc_context* c, const uint8_t* const* frames, bool on_device, int n_frames, int width, int height,
+                                  const double* quant, uint8_t** bytes, size_t* nbytes) {
+    if (!c || !frames || !bytes || !nbytes || n_frames < 1) return fail(MPC_ERR_ARGUMENT, "bad argument");
     if (c->device < 0) return fail(MPC_ERR_NO_DEVICE, "context was created without a device; there is no CPU fallback");
     if (width < 1 || height < 1) return fail(MPC_ERR_ARGUMENT, "bad geometry");
     for (int f = 0; f < n_frames; ++f) {
-        if (!rgb_frames[f]) return fail(MPC_ERR_ARGUMENT, "null frame");
+        if (!frames[f]) return fail(MPC_ERR_ARGUMENT, "null frame");
         bytes[f] = nullptr;
         nbytes[f] = 0;
     }
     const int tiles_y = (height + 7) / 8;
     const size_t tiles = static_cast<size_t>((width + 7) / 8) * tiles_y;
     const size_t n_tc = tiles * 3;
+    const int K = c->K;
     std::lock_guard<std::recursive_mutex> one_host_call(c->host_calls);
     HIP_TRY(hipSetDevice(c->device));
-    // Three stages over kSeqSlots slots: while the device encodes frame f (compute stream), frame f+1 is uploaded
-    // (upload stream, via the slot's pinned image), the records of frame f-1 travel
-    // to pinned host memory (download stream) and workers code earlier frames into their containers.  This thread only
-    // waits for the entropy stage of frame f - kSeqSlots, so it stays ahead of the device.
     auto up = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
     const size_t img_bytes = static_cast<size_t>(3) * width * height;
-    const size_t counts_bytes = up(sizeof(uint16_t) * n_tc), choices_bytes = up(sizeof(mpc_basis_choice) * n_tc * c->K);
-    const size_t host_slot = up(img_bytes) + counts_bytes + choices_bytes;    // image | counts | planar records
-    const size_t dev_slot = host_slot + choices_bytes;                        // image | counts | records | planar records
+    const size_t counts_bytes = up(sizeof(uint16_t) * n_tc), choices_bytes = up(sizeof(mpc_basis_choice) * n_tc * K);
+    const size_t off_bytes = up(sizeof(unsigned long long) * (6 * static_cast<size_t>(K) + 1));
+    const size_t symbols_bytes = up(sizeof(uint16_t) * 2 * n_tc * K);            // worst case: every record alive
+    const size_t live_bytes = up(sizeof(unsigned) * mpc::stream_workspace_words(static_cast<long long>(tiles), K));
+    const size_t sizes_bytes = up(sizeof(unsigned) * 3 * K), dc_bytes = up(sizeof(uint16_t) * n_tc);
+    // host slot: image | counts | stream offsets | symbols;  device slot: image | counts | records | block_live | sizes | offsets | symbols | dc
+    const size_t host_slot = (on_device ? 0 : up(img_bytes)) + counts_bytes + off_bytes + symbols_bytes;
+    const size_t dev_slot = (on_device ? 0 : up(img_bytes)) + counts_bytes + choices_bytes + live_bytes + sizes_bytes + off_bytes + symbols_bytes + dc_bytes;
     constexpr size_t S = mpc_context::kSeqSlots;
-    if (S * host_slot > c->host_stage_bytes) {
+    const size_t slots = std::min<size_t>(S, static_cast<size_t>(n_frames));
+    if (slots * host_slot > c->host_stage_bytes) {
         if (c->host_stage) (void)hipHostFree(c->host_stage);
         c->host_stage = nullptr;
         c->host_stage_bytes = 0;
-        const hipError_t e = hipHostMalloc(&c->host_stage, S * host_slot, hipHostMallocDefault);
-        if (e != hipSuccess) return fail(MPC_ERR_ALLOC, "pinned staging of %zu bytes: %s", S * host_slot, hipGetErrorString(e));
-        c->host_stage_bytes = S * host_slot;
+        const hipError_t e = hipHostMalloc(&c->host_stage, slots * host_slot, hipHostMallocDefault);
+        if (e != hipSuccess) return fail(MPC_ERR_ALLOC, "pinned staging of %zu bytes: %s", slots * host_slot, hipGetErrorString(e));
+        c->host_stage_bytes = slots * host_slot;
     }
-    if (S * dev_slot > c->stage_bytes) {
+    if (slots * dev_slot > c->stage_bytes) {
         if (c->stage) (void)hipFree(c->stage);
         c->stage = nullptr;
         c->stage_bytes = 0;
-        const hipError_t e = hipMalloc(&c->stage, S * dev_slot);
-        if (e != hipSuccess) return fail(MPC_ERR_ALLOC, "device staging of %zu bytes: %s", S * dev_slot, hipGetErrorString(e));
-        c->stage_bytes = S * dev_slot;
+        const hipError_t e = hipMalloc(&c->stage, slots * dev_slot);
+        if (e != hipSuccess) return fail(MPC_ERR_ALLOC, "device staging of %zu bytes: %s", slots * dev_slot, hipGetErrorString(e));
+        c->stage_bytes = slots * dev_slot;
     }
     if (!c->seq_up) {
         HIP_TRY(hipStreamCreateWithFlags(&c->seq_up, hipStreamNonBlocking));
         HIP_TRY(hipStreamCreateWithFlags(&c->seq_compute, hipStreamNonBlocking));
-        HIP_TRY(hipStreamCreateWithFlags(&c->seq_down, hipStreamNonBlocking));
+        for (auto& s : c->seq_down) HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
         for (auto& slot : c->seq_events)
             for (hipEvent_t& e : slot) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
-    // with the upload and download streams busy next to the pursuit, two sub-batch streams per frame measured faster
-    // than the three or four a lone frame uses (the runtime multiplexes all streams onto four hardware queues)
-    struct PipesCap {
-        mpc_context* c;
-        explicit PipesCap(mpc_context* c_) : c(c_) { c->pipes_cap = 2; }
-        ~PipesCap() { c->pipes_cap = 0; }
-    } pipes_cap(c);
     HIP_TRY(ensure_workspace(c, static_cast<long long>(n_tc)) == MPC_OK ? hipSuccess : hipErrorOutOfMemory);
     const double* q = quant ? quant : c->quant.data();
     struct Pending {
@@ -1113,30 +1079,25 @@ mpc_status mpc_encode_images(mpc_context* c, const uint8_t* const* rgb_frames, i
         const hipError_t e_ = (call);                                                             \
         if (e_ != hipSuccess) { st = fail(MPC_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); break; } \
     }
-    bool used[S] = {};                                            // the slot's events have been recorded at least once
     for (int f = 0; f < n_frames && st == MPC_OK; ++f) {
-        const int sl = f % static_cast<int>(S);
+        const int sl = f % static_cast<int>(slots);
         Pending& slot = pending[sl];
-        collect(slot);                                            // frame f-S has left this slot's pinned buffer
+        collect(slot);                    // frame f - slots is done with this slot: its download and its entropy stage have finished
         if (st != MPC_OK) break;
         char* dbase = static_cast<char*>(c->stage) + static_cast<size_t>(sl) * dev_slot;
-        uint8_t* d_rgb = reinterpret_cast<uint8_t*>(dbase);
-        uint16_t* d_counts = reinterpret_cast<uint16_t*>(dbase + up(img_bytes));
-        mpc_basis_choice* d_choices = reinterpret_cast<mpc_basis_choice*>(dbase + up(img_bytes) + counts_bytes);
         char* hbase = static_cast<char*>(c->host_stage) + static_cast<size_t>(sl) * host_slot;
-        uint8_t* pinned_rgb = reinterpret_cast<uint8_t*>(hbase);
-        uint16_t* counts = reinterpret_cast<uint16_t*>(hbase + up(img_bytes));
-        mpc_basis_choice* choices = reinterpret_cast<mpc_basis_choice*>(hbase + up(img_bytes) + counts_bytes);
-        hipEvent_t ev_up = c->seq_events[sl][0], ev_comp = c->seq_events[sl][1], ev_down = c->seq_events[sl][2];
-        // upload: the pursuit of frame f-S must be done with this slot's image
-        if (used[sl]) MPC_SEQ_TRY(hipStreamWaitEvent(c->seq_up, ev_comp, 0));
-        // the caller's frame is pageable: the runtime would stage it through one thread at a few GB/s while this
-        // thread waits; a few threads copy it into the slot's pinned image instead and the DMA runs asynchronously
-        {
+        const uint8_t* d_rgb = frames[f];
+        if (!on_device) {
+            uint8_t* d_img = reinterpret_cast<uint8_t*>(dbase);
+            uint8_t* pinned_rgb = reinterpret_cast<uint8_t*>(hbase);
+            dbase += up(img_bytes);
+            hbase += up(img_bytes);
+            // the caller's frame is pageable: the runtime would stage it through one thread at a few GB/s while this thread
+            // waits; a few threads copy it into the slot's pinned image instead and the DMA runs asynchronously
             constexpr int kCopiers = 4;
             const size_t piece = ((img_bytes + kCopiers - 1) / kCopiers + 4095) & ~static_cast<size_t>(4095);
             std::future<void> parts[kCopiers];
-            const uint8_t* src = rgb_frames[f];
+            const uint8_t* src = frames[f];
             for (int k = 1; k < kCopiers; ++k) {
                 const size_t lo = std::min(img_bytes, piece * k), hi = std::min(img_bytes, piece * (k + 1));
                 if (hi > lo) parts[k] = std::async(std::launch::async, [=] { std::memcpy(pinned_rgb + lo, src + lo, hi - lo); });
@@ -1144,44 +1105,84 @@ mpc_status mpc_encode_images(mpc_context* c, const uint8_t* const* rgb_frames, i
             std::memcpy(pinned_rgb, src, std::min(img_bytes, piece));
             for (int k = 1; k < kCopiers; ++k)
                 if (parts[k].valid()) parts[k].get();
+            MPC_SEQ_TRY(hipMemcpyAsync(d_img, pinned_rgb, img_bytes, hipMemcpyHostToDevice, c->seq_up));
+            MPC_SEQ_TRY(hipEventRecord(c->seq_events[sl][0], c->seq_up));
+            MPC_SEQ_TRY(hipStreamWaitEvent(c->seq_compute, c->seq_events[sl][0], 0));
+            d_rgb = d_img;
         }
-        MPC_SEQ_TRY(hipMemcpyAsync(d_rgb, pinned_rgb, img_bytes, hipMemcpyHostToDevice, c->seq_up));
-        MPC_SEQ_TRY(hipEventRecord(ev_up, c->seq_up));
-        // compute: after the upload, and after frame f-S's records have left the device buffers
-        MPC_SEQ_TRY(hipStreamWaitEvent(c->seq_compute, ev_up, 0));
-        if (used[sl]) MPC_SEQ_TRY(hipStreamWaitEvent(c->seq_compute, ev_down, 0));
+        uint16_t* d_counts = reinterpret_cast<uint16_t*>(dbase);
+        mpc_basis_choice* d_choices = reinterpret_cast<mpc_basis_choice*>(dbase + counts_bytes);
+        mpc::StreamArgs sa{};
+        sa.counts = d_counts;
+        sa.choices = reinterpret_cast<const uint32_t*>(d_choices);
+        sa.tiles = static_cast<long long>(tiles);
+        sa.K = K;
+        sa.block_live = reinterpret_cast<unsigned*>(dbase + counts_bytes + choices_bytes);
+        sa.sizes = reinterpret_cast<unsigned*>(dbase + counts_bytes + choices_bytes + live_bytes);
+        sa.stream_off = reinterpret_cast<unsigned long long*>(dbase + counts_bytes + choices_bytes + live_bytes + sizes_bytes);
+        sa.symbols = reinterpret_cast<uint16_t*>(dbase + counts_bytes + choices_bytes + live_bytes + sizes_bytes + off_bytes);
+        sa.dc_tmp = reinterpret_cast<uint16_t*>(dbase + counts_bytes + choices_bytes + live_bytes + sizes_bytes + off_bytes + symbols_bytes);
+        uint16_t* counts = reinterpret_cast<uint16_t*>(hbase);
+        unsigned long long* off = reinterpret_cast<unsigned long long*>(hbase + counts_bytes);
+        uint16_t* symbols = reinterpret_cast<uint16_t*>(hbase + counts_bytes + off_bytes);
         st = mpc_encode_tiles_device(c, d_rgb, width, height, static_cast<size_t>(3) * width, 0, tiles_y, quant, d_counts, d_choices,
                                      nullptr, nullptr, 0, c->seq_compute);
         if (st != MPC_OK) break;
-        uint32_t* d_planar = reinterpret_cast<uint32_t*>(dbase + up(img_bytes) + counts_bytes + choices_bytes);
-        MPC_SEQ_TRY(static_cast<hipError_t>(mpc::launch_planar_records(reinterpret_cast<const uint32_t*>(d_choices), d_planar,
-                                                                     static_cast<long long>(tiles), c->K, c->seq_compute)));
+        MPC_SEQ_TRY(static_cast<hipError_t>(mpc::launch_stream_assembly(sa, c->seq_compute)));
+        hipEvent_t ev_comp = c->seq_events[sl][1];
         MPC_SEQ_TRY(hipEventRecord(ev_comp, c->seq_compute));
-        // download into the pinned slot
-        MPC_SEQ_TRY(hipStreamWaitEvent(c->seq_down, ev_comp, 0));
-        MPC_SEQ_TRY(hipMemcpyAsync(counts, d_counts, sizeof(uint16_t) * n_tc, hipMemcpyDeviceToHost, c->seq_down));
-        MPC_SEQ_TRY(hipMemcpyAsync(choices, d_planar, sizeof(mpc_basis_choice) * n_tc * c->K, hipMemcpyDeviceToHost, c->seq_down));
-        MPC_SEQ_TRY(hipEventRecord(ev_down, c->seq_down));
-        used[sl] = true;
-        const int K = c->K, bs = c->block_size, device = c->device;
+        const int bs = c->block_size, device = c->device;
+        hipStream_t down = c->seq_down[sl];
+        const uint16_t* d_symbols = sa.symbols;
+        const unsigned long long* d_off = sa.stream_off;
+        const size_t n_off = 6 * static_cast<size_t>(K) + 1;
         slot.frame = f;
+        // the slot's worker: wait for the device, fetch the stream boundaries, then exactly the live symbols, then code them
         slot.result = std::async(std::launch::async, [=]() -> std::pair<uint8_t*, size_t> {
-            if (hipSetDevice(device) != hipSuccess || hipEventSynchronize(ev_down) != hipSuccess) return {nullptr, 0};
+            if (hipSetDevice(device) != hipSuccess || hipStreamWaitEvent(down, ev_comp, 0) != hipSuccess) return {nullptr, 0};
+            if (hipMemcpyAsync(off, d_off, sizeof(unsigned long long) * n_off, hipMemcpyDeviceToHost, down) != hipSuccess) return {nullptr, 0};
+            if (hipMemcpyAsync(counts, d_counts, sizeof(uint16_t) * n_tc, hipMemcpyDeviceToHost, down) != hipSuccess) return {nullptr, 0};
+            if (hipStreamSynchronize(down) != hipSuccess) return {nullptr, 0};
+            const unsigned long long total = off[n_off - 1];
+            if (total > 2ULL * n_tc * static_cast<unsigned long long>(K)) return {nullptr, 0};
+            if (total && hipMemcpyAsync(symbols, d_symbols, sizeof(uint16_t) * total, hipMemcpyDeviceToHost, down) != hipSuccess) return {nullptr, 0};
+            if (hipStreamSynchronize(down) != hipSuccess) return {nullptr, 0};
             size_t n = 0;
-            uint8_t* blob = mpc::encode_planar_records_malloc(width, height, K, bs, q, counts, reinterpret_cast<const uint32_t*>(choices), &n);
+            uint8_t* blob = mpc::encode_symbol_streams_malloc(width, height, K, bs, q, counts, symbols, off, &n);
             return {blob, n};
         });
     }
 #undef MPC_SEQ_TRY
-    for (int f = n_frames; f < n_frames + static_cast<int>(S); ++f) collect(pending[f % static_cast<int>(S)]);   // oldest first
+    for (int f = n_frames; f < n_frames + static_cast<int>(slots); ++f) collect(pending[f % static_cast<int>(slots)]);   // oldest first
     (void)hipStreamSynchronize(c->seq_up);
     (void)hipStreamSynchronize(c->seq_compute);
-    (void)hipStreamSynchronize(c->seq_down);
     if (st != MPC_OK) {
         for (int f = 0; f < n_frames; ++f) { std::free(bytes[f]); bytes[f] = nullptr; nbytes[f] = 0; }
     }
     return st;
-    });
+}
+
+mpc_status mpc_encode_images(mpc_context* c, const uint8_t* const* rgb_frames, int n_frames, int width, int height,
+                             const double* quant, uint8_t** bytes, size_t* nbytes) {
+    return guarded([&]() -> mpc_status { return encode_sequence(c, rgb_frames, false, n_frames, width, height, quant, bytes, nbytes); });
+}
+
+mpc_status mpc_encode_images_device(mpc_context* c, const uint8_t* const* d_rgb_frames, int n_frames, int width, int height,
+                                    const double* quant, uint8_t** bytes, size_t* nbytes) {
+    return guarded([&]() -> mpc_status { return encode_sequence(c, d_rgb_frames, true, n_frames, width, height, quant, bytes, nbytes); });
+}
+
+// compressed::encodeImage: one frame through the same stages
+mpc_status mpc_encode_image(mpc_context* c, const uint8_t* rgb, int width, int height, const double* quant,
+                            uint8_t** bytes, size_t* nbytes) {
+    if (!rgb || !bytes || !nbytes) return fail(MPC_ERR_ARGUMENT, "null argument");
+    return guarded([&]() -> mpc_status { return encode_sequence(c, &rgb, false, 1, width, height, quant, bytes, nbytes); });
+}
+
+mpc_status mpc_encode_image_device(mpc_context* c, const uint8_t* d_rgb, int width, int height, const double* quant,
+                                   uint8_t** bytes, size_t* nbytes) {
+    if (!d_rgb || !bytes || !nbytes) return fail(MPC_ERR_ARGUMENT, "null argument");
+    return guarded([&]() -> mpc_status { return encode_sequence(c, &d_rgb, true, 1, width, height, quant, bytes, nbytes); });
 }
 
 // FromCoeffsDynamic + RGBFromYUV for whole tiles on the device; d_quant: [3][K] doubles on the device

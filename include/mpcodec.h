@@ -25,6 +25,7 @@
  *   mpc_read_compressed       compressed::readCompressed                  CompressedImage.cpp:635
  *   mpc_encode_image          compressed::encodeImage                     CompressedImage.h:59
  *   mpc_encode_images         (same, a sequence of frames, host and device stages overlapped)
+ *   mpc_encode_image(s)_device (same, frames already in device memory)
  *   mpc_decode_image          compressed::decodeImage                     CompressedImage.h:75
  *   mpc_decode_tiles_device   matching::FromCoeffsDynamic per tile        MatchingPursuit.h:25, CompressedImage.cpp:797-831
  *   mpc_psnr                  compressed::calculatePSNR                   CompressedImage.h:57
@@ -197,6 +198,13 @@ mpc_status mpc_encode_image(mpc_context* ctx, const uint8_t* rgb, int width, int
  * returned. */
 mpc_status mpc_encode_images(mpc_context* ctx, const uint8_t* const* rgb_frames, int n_frames, int width, int height,
                              const double* quant, uint8_t** bytes, size_t* nbytes);
+
+/* The same two with the frames already resident in device memory (3*width bytes per row, tightly packed): what bench.py
+ * times -- tile encode and stream assembly on the device, only the live symbols cross PCIe, entropy stage on the host. */
+mpc_status mpc_encode_image_device(mpc_context* ctx, const uint8_t* d_rgb, int width, int height, const double* quant,
+                                   uint8_t** bytes, size_t* nbytes);
+mpc_status mpc_encode_images_device(mpc_context* ctx, const uint8_t* const* d_rgb_frames, int n_frames, int width, int height,
+                                    const double* quant, uint8_t** bytes, size_t* nbytes);
 
 /* matching::FromCoeffsDynamic (MatchingPursuit.h:25) + img::RGBFromYUV for every tile of a frame on the device:
  * records in the reference's order (tile t = tx*tiles_y + ty, as mpc_encode_tiles returns them for the whole

@@ -574,3 +574,19 @@ def test_quant_override_does_not_stick(ctx32, octx32, oracle):
     # decode side: an override on mpc_decode_tiles_device must not stick either
     back = ia.api.decode_image(want, ctx32)
     assert (back == oracle.decode_image(want)).all()
+
+
+def test_device_resident_frames_to_containers(gpu, oracle):
+    """mpc_encode_image(s)_device: frames already in HBM -> tile encode + stream assembly on the device -> host entropy stage.
+    Same bytes as the oracle's encodeImage, for several K (record alignment), ragged sizes and more frames than slots."""
+    import imageexperiments_amd as ia
+    for (w, h, K, q, n) in ((200, 136, 32, 3.5, 6), (129, 77, 8, 3.5, 3), (64, 64, 5, 2.0, 2), (1003, 517, 16, 4.0, 1)):
+        ctx = ia.create_compression_context(K, 8, q, device=0)
+        octx = oracle.OracleContext(K, 8, q)
+        frames = [oracle.synth_frame(w, h, 40 + f) for f in range(n)]
+        d = [gpu.from_numpy(f).cuda() for f in frames]
+        blobs = ctx.encode_images_device([t.data_ptr() for t in d], w, h)
+        for f in range(n):
+            assert bytes(blobs[f]) == bytes(octx.encode_image(frames[f])), (w, h, K, f)
+        assert bytes(ctx.encode_image_device(d[0].data_ptr(), w, h)) == bytes(blobs[0])
+        ctx.close()
