@@ -1,14 +1,18 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark of the MI355X tile encoder (BASELINE.json metric).
+"""bench.py -- headline benchmark of the MI355X tile encoder (BASELINE.json metric: encode Mpixels/s at quality 3.5).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 1080p|raise|8k] [--no-cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload raise|1080p|8k] [--quality Q] [--no-cpu]
 
-A *step* is one pass of the hot path (RGB frame(s) resident in HBM -> per-tile matching-pursuit records
-in HBM -> per-stream symbol histograms [-> RCCL all-reduce of the histograms when N > 1]).
-N = 1: one synthetic 1920x1080 frame, K = 8, quality 3.5 (BASELINE.json configs[1]).
-N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling -- a batch of N such frames per
-step, every frame row-striped over the N ranks (rank r encodes stripe r of each frame, one launch), no
-data-path collective except the histogram all-reduce that feeds the Huffman/Golomb tables.
+A *step* is one pass of the hot path over one batch of synthetic frames that are already resident in HBM:
+RGB in HBM -> tile encode (mp_pursuit_kernel, one launch) -> stream assembly on the device -> the live symbols
+to the host -> entropy stage -> container bytes (byte-identical to the reference's encodeImage; tests/test_gpu_golden_frames.py).
+N = 1: one frame per step; default workload = the north_star's: 4928x3264 synthetic RGB, K = 32, quality 3.5.  The K steps
+of the timed region go through the library's frame pipeline in one call (mpc_encode_images_device): the host entropy stage
+of step i overlaps the device work of step i + 1, as in any steady-state use.
+N > 1 (torch.distributed.run, one rank per GPU): weak scaling, N frames per step.  Every frame is row-striped over the N
+ranks (rank r encodes tile-row stripe r of every frame in one launch); the stripes' records then travel to the frame's owner
+(rank f owns frame f: batched point-to-point over RCCL/xGMI), which interleaves them into the reference's tile order and
+produces frame f's container.  No other collective: see DESIGN.md 7 for why the symbol-histogram all-reduce is not in it.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -25,12 +29,12 @@ sys.path.insert(0, ROOT)
 WORKLOADS = {
     # name: (W, H, K, quality)   -- BASELINE.json configs
     "1080p": (1920, 1080, 8, 3.5),     # configs[1]
-    "raise": (4928, 3264, 32, 3.5),    # configs[2] at the quality the metric names
+    "raise": (4928, 3264, 32, 3.5),    # configs[2] at the quality the metric and the north_star name
     "8k": (7680, 4320, 16, 3.5),       # configs[4]
 }
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-F64_VALU_PEAK_GOPS = 256 * 4 * 16 * 2.4  # 256 CU x 4 SIMD x 16 f64 lanes/clk x 2.4 GHz = 39 321 G instr-lanes/s
 BF16_MFMA_PEAK_TFLOPS = 2516.8         # MI355X_MICROARCH.md: dense bf16 MFMA = 16 x the 157.3 TF f32 rate
+MFMA_FLOP = 2 * 16 * 16 * 32           # one v_mfma_f32_16x16x32_bf16
 
 
 def synth_frame(W, H, seed):
@@ -56,6 +60,78 @@ def synth_frame(W, H, seed):
     return out
 
 
+# ---- cpu_baseline: the oracle (plain-C port of the reference's double path), one core and all cores ----------------------
+_cpu = {}
+
+
+def _cpu_init(K, q, shm_name, shape):
+    from multiprocessing import shared_memory
+    from oracle import oracle_py as O
+    shm = shared_memory.SharedMemory(name=shm_name)
+    _cpu["ctx"] = O.OracleContext(K, 8, q)
+    _cpu["shm"] = shm
+    _cpu["rgb"] = np.ndarray(shape, np.uint8, buffer=shm.buf)
+
+
+def _cpu_work(rng):
+    _cpu["ctx"].encode_tiles(_cpu["rgb"], tx_begin=rng[0], tx_end=rng[1])
+    return rng[1] - rng[0]
+
+
+def host_cores():
+    """Cores this process may really use: the affinity mask, cut down to the cgroup's CPU quota where there is one (a GPU
+    box hands a one-GPU job a share of the host's cores, not all of them)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return min(n, 64)
+
+
+def cpu_baseline(W, H, K, q, frame, seconds):
+    """Bounded sample of the same frame: tile columns 0..c-1 on ONE core, then tile columns on ALL host cores (one process per
+    core, tile-column parallel), each sized for about `seconds` of work from a short calibration."""
+    import multiprocessing as mp
+    from multiprocessing import shared_memory
+    from oracle import oracle_py as O
+    O.build(ref=False)
+    octx = O.OracleContext(K, 8, q)
+    tiles_x, tiles_y = (W + 7) // 8, (H + 7) // 8
+    t0 = time.perf_counter()
+    octx.encode_tiles(frame, tx_begin=0, tx_end=2)
+    per_col = (time.perf_counter() - t0) / 2
+    c1 = int(max(2, min(tiles_x, seconds / per_col)))
+    t0 = time.perf_counter()
+    octx.encode_tiles(frame, tx_begin=0, tx_end=c1)
+    dt1 = time.perf_counter() - t0
+    one = c1 * tiles_y * 64 / dt1 / 1e6
+    cores = host_cores()
+    call = int(max(cores, min(tiles_x, cores * seconds / per_col)))
+    shm = shared_memory.SharedMemory(create=True, size=frame.nbytes)
+    try:
+        np.ndarray(frame.shape, np.uint8, buffer=shm.buf)[:] = frame
+        step = max(1, call // (cores * 4))
+        ranges = [(a, min(a + step, call)) for a in range(0, call, step)]
+        with mp.get_context("fork").Pool(cores, initializer=_cpu_init, initargs=(K, q, shm.name, frame.shape)) as pool:
+            pool.map(_cpu_work, [(0, 1)] * cores)                          # contexts built, pages touched
+            t0 = time.perf_counter()
+            pool.map(_cpu_work, ranges, chunksize=1)
+            dta = time.perf_counter() - t0
+    finally:
+        shm.close()
+        shm.unlink()
+    allc = call * tiles_y * 64 / dta / 1e6
+    return {"value": round(allc, 5), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+            "sample": f"tile columns 0..{call - 1} of the same {W}x{H} frame over {cores} processes ({call * tiles_y} tiles, {dta:.1f} s)",
+            "one_core": {"value": round(one, 5), "cores": 1, "sample": f"tile columns 0..{c1 - 1} ({c1 * tiles_y} tiles, {dt1:.1f} s)"},
+            "note": "oracle/mpo_*.c = C restatement of the reference's double path (tile encode only, no entropy stage) without its "
+                    "per-step dictionary copy: about twice as fast as the reference itself (0.0707 Mpix/s on one core of the dev "
+                    "container, SURVEY 6); the reference is single-threaded, its Eigen/float path is not buildable here"}
+
+
 def stripe_bounds(tiles_y, n, r):
     """contiguous tile-row stripes, remainder to the first ranks (540 -> 68x4 + 67x4)."""
     base, rem = divmod(tiles_y, n)
@@ -63,32 +139,15 @@ def stripe_bounds(tiles_y, n, r):
     return begin, begin + base + (1 if r < rem else 0)
 
 
-def cpu_baseline(W, H, K, q, frame, budget_cols):
-    """The oracle (plain-C port of the reference's double path) on one host core, bounded sample."""
-    from oracle import oracle_py as O
-    O.build(ref=False)
-    octx = O.OracleContext(K, 8, q)
-    tiles_y = (H + 7) // 8
-    cols = min(budget_cols, (W + 7) // 8)
-    t0 = time.perf_counter()
-    octx.encode_tiles(frame, tx_begin=0, tx_end=cols)
-    dt = time.perf_counter() - t0
-    px = cols * tiles_y * 64
-    return {"value": round(px / dt / 1e6, 5), "unit": "Mpixels/s", "cores": 1, "kind": "port",
-            "sample": f"tile columns 0..{cols - 1} of the same {W}x{H} frame ({cols * tiles_y} tiles, {dt:.1f} s); "
-                      "oracle/mpo_*.c = C restatement of the reference's double path without its per-step dictionary copy "
-                      "(the reference itself measured 0.0707 Mpix/s here, SURVEY 6); Eigen/float path not buildable"}
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="1080p", choices=sorted(WORKLOADS))
-    ap.add_argument("--waves", type=int, default=0, help="grid size in wave64 workgroups (0 = automatic)")
+    ap.add_argument("--workload", default="raise", choices=sorted(WORKLOADS))
+    ap.add_argument("--quality", type=float, default=None, help="bpp allocation (BASELINE configs[2] sweeps 2.0 .. 6.0); default 3.5")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--cpu-cols", type=int, default=160, help="tile columns in the CPU sample")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="target duration of each CPU sample")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo + --share-device rehearses the N>1 path on a one-GPU box")
     ap.add_argument("--share-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
@@ -97,13 +156,13 @@ def main():
     import torch
     import torch.distributed as dist
     import imageexperiments_amd as ia
+    from imageexperiments_amd import sharding
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the hot path has no CPU fallback")
     if args.share_device:
@@ -117,97 +176,119 @@ def main():
             dist.init_process_group("gloo")
 
     W, H, K, q = WORKLOADS[args.workload]
+    if args.quality is not None:
+        q = args.quality
     ctx = ia.create_compression_context(K, 8, q, device=local_rank)
     tiles_x, tiles_y = (W + 7) // 8, (H + 7) // 8
     frames = world                                           # weak scaling: N frames per step for N ranks
-    row_begin, row_end = stripe_bounds(tiles_y, world, rank)
-    rows = row_end - row_begin
-    tiles = frames * tiles_x * rows                          # tiles this rank encodes per step
-
     host_frames = np.stack([synth_frame(W, H, 12345 + f) for f in range(frames)])
     d_rgb = torch.from_numpy(host_frames).cuda()
-    d_counts = torch.zeros((tiles, 3), dtype=torch.int16, device="cuda")
-    d_choices = torch.zeros((tiles, 3, K), dtype=torch.int32, device="cuda")
-    d_energy = torch.zeros((tiles, 3), dtype=torch.float64, device="cuda")
-    d_swept = torch.zeros((tiles, 3), dtype=torch.int32, device="cuda")
-    d_hist = torch.zeros((1 + 6 * K, ia.api.HIST_BINS), dtype=torch.int32, device="cuda")
-    ctx.reserve(tiles)
     stream = torch.cuda.current_stream()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-
-    def step(i=None):
-        d_hist.zero_()
-        if i is not None:
-            ev[i][0].record(stream)
-        ctx.encode_batch_device(d_rgb.data_ptr(), frames, W * H * 3, W, H, W * 3, row_begin, row_end,
-                                d_counts.data_ptr(), d_choices.data_ptr(), d_energy.data_ptr(), d_swept.data_ptr(),
-                                waves=args.waves, stream=stream.cuda_stream)
-        if i is not None:
-            ev[i][1].record(stream)
-        ctx.histogram_device(d_counts.data_ptr(), d_choices.data_ptr(), tiles, d_hist.data_ptr(), stream=stream.cuda_stream)
-        if world > 1:
-            if args.backend == "nccl":
-                dist.all_reduce(d_hist)                      # the path's only exchange
-            else:
-                h = d_hist.cpu()
-                dist.all_reduce(h)
-                d_hist.copy_(h)
+    containers = []
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    if world == 1:
+        ptr = d_rgb.data_ptr()
+
+        def run(n):                                          # n steps = n frames through the pipeline, in one call
+            return ctx.encode_images_device([ptr] * n, W, H)
+    else:
+        striped = sharding.StripedEncoder(ctx, W, H, frames, world, rank, args.backend)
+
+        def run(n):
+            out = []
+            for _ in range(n):
+                out.append(striped.step(d_rgb, stream))
+            return out
+
+    run(args.warmup)
     fence()
-    ctx.kernel_timing(True)                                  # HIP events around every launch of the dominant kernel
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
+    containers = run(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    container_bytes = len(containers[-1])
 
-    base_ms_total, base_launches, base_busy_ms = ctx.read_kernel_timing()   # dominant kernel, HIP events on its launch streams
+    # ---- untimed: the device stage alone, with HIP events around every launch of the dominant kernel -------------------------
+    row_begin, row_end = stripe_bounds(tiles_y, world, rank)
+    tiles = frames * tiles_x * (row_end - row_begin)
+    d_counts = torch.zeros((tiles, 3), dtype=torch.int16, device="cuda")
+    d_choices = torch.zeros((tiles, 3, K), dtype=torch.int32, device="cuda")
+    d_swept = torch.zeros((tiles, 3), dtype=torch.int32, device="cuda")
+    dev_steps = max(3, min(args.steps, 10))
+
+    def device_stage():
+        ctx.encode_batch_device(d_rgb.data_ptr(), frames, W * H * 3, W, H, W * 3, row_begin, row_end, d_counts.data_ptr(),
+                                d_choices.data_ptr(), 0, d_swept.data_ptr(), stream=stream.cuda_stream)
+    device_stage()
+    torch.cuda.synchronize()
+    ctx.kernel_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(dev_steps):
+        device_stage()
+    torch.cuda.synchronize()
+    dev_elapsed = (time.perf_counter() - t0) / dev_steps
+    kern_ms_total, kern_launches, kern_busy_ms = ctx.read_kernel_timing()
+    mfma_instr, tc_steps = ctx.read_kernel_counters()
     ctx.kernel_timing(False)
-    pursuit_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))     # all kernels of one step's K-step pursuit
-    swept_total = int(d_swept.to(torch.int64).sum().item())             # S summed over this rank's tile-channels
-    # tile-channels active in pursuit step s = those with count >= s (count = K: all K steps)
-    cnt_hist = torch.bincount(d_counts.to(torch.int64).flatten().clamp(0, K), minlength=K + 1).cpu().numpy()
-    active = np.array([int(cnt_hist[s:].sum()) for s in range(K)], dtype=np.int64)
-    sweeps = int(active.sum())                                          # = sum over tile-channels of min(count+1, K)
-    # The dominant kernel (mp_filter_wave_kernel) runs the base rows (512 with the zero pads; + 64 of DetailBasis[0] from
-    # step 1 on) of every active tile-channel through the matrix cores, each product as three bf16 MFMAs (hi*hi + hi*lo +
-    # lo*hi): executed MFMA flops per launch >= 3 x 2*64*rows x tile-channels (a second pass only for the column groups
-    # where a runner-up reaches the threshold, ~1 % of the tile-channels: not counted).
-    rows_per_step = np.array([512 + (64 if s > 0 else 0) for s in range(K)], dtype=np.int64)
-    mfma_flops_per_step = float((active * rows_per_step).sum()) * 3 * 2 * 64
-    # what the reference's algorithm asks of the same rows: one 64-term dot product per (tile-channel, row)
-    algorithmic_flops_per_step = float((active * np.array([510 + (63 if s > 0 else 0) for s in range(K)])).sum()) * 2 * 64
-    base_ms = base_ms_total / max(base_launches, 1)                     # average duration of ONE launch of it
-    # launches on the internal streams overlap, so the machine-level rate of this kernel is work over the UNION of its
-    # launch intervals (equals work-per-launch / average duration when nothing overlaps)
-    achieved_tflops = mfma_flops_per_step * args.steps / (base_busy_ms * 1e-3) / 1e12
-    sweep_bytes = 64 * 8 * swept_total                                  # 64 * sizeof(double) per row correlated
-    kernel_bytes_per_step = algorithmic_flops_per_step / 2.0 * 8.0      # 64 * 8 bytes per row = 4 bytes per reference flop
-    kernel_gbs = kernel_bytes_per_step * args.steps / (base_busy_ms * 1e-3) / 1e9
+    swept_total = int(d_swept.to(torch.int64).sum().item())
 
     if rank == 0:
         pixels_per_step = frames * W * H
         value = pixels_per_step * args.steps / elapsed / 1e6
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", f"r01_pmc_{args.workload}.json")
-        if os.path.exists(pmc):
+        launches_per_step = kern_launches // dev_steps
+        flops_per_launch = mfma_instr * MFMA_FLOP / max(kern_launches, 1)
+        avg_ms = kern_ms_total / max(kern_launches, 1)
+        mfma_tflops = flops_per_launch / (avg_ms * 1e-3) / 1e12
+        # HBM traffic of the same kernel from separate rocprofv3 --pmc passes at this commit (tools/profile_round.sh)
+        traffic = traffic_src = None
+        hbm_gbs = None
+        pmc = os.path.join(ROOT, "profiles", f"r02_pmc_{args.workload}.json")
+        if args.quality is None and world == 1 and os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                rec = json.load(open(pmc))
+                traffic = rec.get("mp_pursuit_kernel", {}).get("hbm_bytes_per_launch")
+                traffic_src = "profiles/" + os.path.basename(pmc)
+                if traffic:
+                    hbm_gbs = traffic / (avg_ms * 1e-3) / 1e9
             except Exception:
                 traffic = None
+        mfma_frac = mfma_tflops / BF16_MFMA_PEAK_TFLOPS
+        hbm_frac = (hbm_gbs or 0.0) / HBM_PEAK_GBS
+        if hbm_frac > mfma_frac:
+            roof = {"bound": "hbm", "achieved": round(hbm_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_frac, 4)}
+        else:
+            roof = {"bound": "mfma", "achieved": round(mfma_tflops, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(mfma_frac, 4)}
+        roof.update({
+            "traffic": traffic, "traffic_source": traffic_src,
+            "kernel": "mp_pursuit_kernel", "kernel_avg_ms": round(avg_ms, 5), "kernel_launches_per_step": launches_per_step,
+            "kernel_busy_ms_per_step": round(kern_busy_ms / dev_steps, 4),
+            "executed_mfma_flops_per_launch": int(flops_per_launch),
+            "mfma_frac": round(mfma_frac, 4), "hbm_frac": round(hbm_frac, 4) if traffic else None,
+            "tile_channel_steps_per_step": tc_steps // dev_steps,
+            "simd_cycles_per_tile_channel_step_at_2p4GHz": round(dev_elapsed / max(tc_steps // dev_steps, 1) * 1024 * 2.4e9, 1),
+            # SURVEY 8(d)'s algorithmic figure, kept for reference only: 64 * sizeof(double) per dictionary row the reference
+            # correlates, over the device stage's time.  It is an algorithmic speed-up over a literal sweep, not a bandwidth:
+            # the rows live in LDS as split-bf16 operands and only one or two per tile-channel-step are touched in double.
+            "equivalent_sweep_GBps": round(64 * 8 * swept_total / dev_elapsed / 1e9, 1),
+            "note": "dominant kernel = mp_pursuit_kernel (one launch per step: "
+                    "kernel_avg_ms is its duration).  achieved = MFMA flops the "
+                    "kernel itself counted (every v_mfma_f32_16x16x32_bf16 executed, 16384 flop each) / its average launch duration "
+                    "(HIP events on the launch stream) against the dense bf16 peak; traffic = HBM bytes per launch from separate "
+                    "rocprofv3 --pmc passes at the same commit (2 x FETCH_SIZE + WRITE_SIZE: the guide's gfx950 correction).  "
+                    "frac = the larger of the two utilisations.  What bounds the kernel is per-step latency, not either roof "
+                    "(DESIGN.md 3, 9)"})
         line = {
-            "metric": "encode Mpixels/s at quality=3.5",
+            "metric": "encode Mpixels/s at quality=3.5" if q == 3.5 else f"encode Mpixels/s at quality={q}",
             "value": round(value, 3),
             "unit": "Mpixels/s",
             "n_gpus": world,
@@ -221,38 +302,17 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{frames} x {W}x{H} synthetic RGB (mt19937 seed 12345+f), quality {q}, K={K} "
                                    "atoms/tile-channel, 8x8 tiles" + (f", row-striped over {world} GPUs" if world > 1 else ""),
-                       "stage": "device tile encode: RGB in HBM -> per-tile MP records + symbol histograms in HBM"
-                                + (" + RCCL all-reduce of the histograms" if world > 1 else "")
-                                + "; host entropy stage (byte-identical container) not in the timed region",
-                       "tiles_per_rank": tiles},
-            # the judge's figure is ALGORITHMIC sweep bytes (64 * sizeof(double) per row the reference correlates)
-            # over the kernel's time, against the HBM peak -- the rows are served by L2 (and most are never touched in
-            # double at all), so it exceeds 1 by design; the PMC traffic and the matrix-core rate stand next to it.
-            "roofline": {"bound": "hbm", "achieved": round(kernel_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(kernel_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "mp_filter_wave_kernel", "kernel_avg_ms": round(base_ms, 5),
-                         "kernel_launches_per_step": base_launches // args.steps,
-                         "kernel_busy_ms_per_step": round(base_busy_ms / args.steps, 4),
-                         "algorithmic_bytes_per_launch": int(kernel_bytes_per_step * args.steps / max(base_launches, 1)),
-                         "mfma": {"executed_TFLOPs": round(achieved_tflops, 2), "peak": BF16_MFMA_PEAK_TFLOPS,
-                                  "frac": round(achieved_tflops / BF16_MFMA_PEAK_TFLOPS, 4),
-                                  "reference_TFLOPs": round(algorithmic_flops_per_step * args.steps / (base_busy_ms * 1e-3) / 1e12, 2)},
-                         "whole_pursuit": {"ms_per_step": round(pursuit_ms, 4), "algorithmic_bytes_per_step": sweep_bytes,
-                                           "GB_per_s": round(sweep_bytes / (pursuit_ms * 1e-3) / 1e9, 1),
-                                           "swept_rows_per_tile": round(swept_total / tiles, 1),
-                                           "tile_channel_steps": sweeps},
-                         "note": "dominant kernel = the filtered sweep of the base rows + DetailBasis[0]: bf16 MFMA approximations of "
-                                 "every row select the one or two rows whose exact double dot product can be the maximum (records stay "
-                                 "bit-identical).  achieved = SURVEY 8(d)'s algorithmic bytes (64*8 per row the reference correlates: "
-                                 "510 base rows + 63 of block 0 from step 1 on, per active tile-channel) over the union of the kernel's "
-                                 "launch intervals; > HBM peak because no dictionary row is fetched from HBM and few are touched in "
-                                 "double.  traffic = PMC FETCH/WRITE bytes of a whole bench step (profiles/r01_pmc_*.json).  mfma = "
-                                 "executed matrix-core flops (3 split-bf16 products per element, the rare second pass not counted) against the dense "
-                                 "bf16 peak; the "
-                                 "kernel is bound by memory latency and the serial exact evaluations (DESIGN.md 3, 9)"},
+                       "stage": "frames resident in HBM -> tile encode + stream assembly on the device -> live symbols to the host -> "
+                                "entropy stage -> container bytes (byte-identical to the reference's encodeImage)"
+                                + ("; stripes' records exchanged between ranks so that rank f produces frame f's container" if world > 1 else
+                                   "; the steps of the timed region are pipelined (entropy stage of step i beside the device work of step i+1)"),
+                       "container_bytes": container_bytes, "bpp": round(8.0 * container_bytes / (W * H), 4)},
+            "device_stage_Mpix_s": round(pixels_per_step / world / dev_elapsed / 1e6, 3) if world > 1 else round(pixels_per_step / dev_elapsed / 1e6, 3),
+            "device_stage_ms": round(dev_elapsed * 1e3, 4),
+            "roofline": roof,
         }
         if not args.no_cpu and world == 1:
-            line["cpu_baseline"] = cpu_baseline(W, H, K, q, host_frames[0], args.cpu_cols)
+            line["cpu_baseline"] = cpu_baseline(W, H, K, q, host_frames[0], args.cpu_seconds)
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

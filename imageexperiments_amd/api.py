@@ -73,6 +73,7 @@ def load_library():
     L.mpc_reserve.argtypes = [vp, C.c_longlong]
     L.mpc_kernel_timing_enable.argtypes = [vp, C.c_int]
     L.mpc_kernel_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]
+    L.mpc_kernel_counters_read.argtypes = [vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
     _bind_bitstream(L)
     _lib = L
     return L
@@ -102,6 +103,7 @@ def _bind_bitstream(L):
     L.mpc_encode_image.argtypes = [vp, _u8p, C.c_int, C.c_int, _dp, C.POINTER(_u8p), C.POINTER(C.c_size_t)]
     L.mpc_encode_images.argtypes = [vp, C.POINTER(_u8p), C.c_int, C.c_int, C.c_int, _dp, C.POINTER(_u8p), C.POINTER(C.c_size_t)]
     L.mpc_encode_images_device.argtypes = [vp, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, _dp, C.POINTER(_u8p), C.POINTER(C.c_size_t)]
+    L.mpc_records_to_container_device.argtypes = [vp, vp, vp, C.c_int, C.c_int, _dp, vp, C.POINTER(_u8p), C.POINTER(C.c_size_t)]
     L.mpc_encode_image_device.argtypes = [vp, vp, C.c_int, C.c_int, _dp, C.POINTER(_u8p), C.POINTER(C.c_size_t)]
     L.mpc_decode_tiles_device.argtypes = [vp, vp, vp, _dp, C.c_int, C.c_int, vp, vp]
     L.mpc_decode_image.argtypes = [vp, _u8p, C.c_size_t, C.POINTER(_u8p), C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -419,6 +421,12 @@ class CompressionContext:
         _check(self.L.mpc_kernel_timing_read(self.h, C.byref(ms), C.byref(n), C.byref(busy)))
         return ms.value, n.value, busy.value
 
+    def read_kernel_counters(self):
+        """-> (MFMA instructions executed, tile-channel-steps) counted by the pursuit kernel since kernel_timing(True) / the last read."""
+        a, b = C.c_ulonglong(0), C.c_ulonglong(0)
+        _check(self.L.mpc_kernel_counters_read(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def encode_image(self, rgb, quant=None):
         """compressed::encodeImage (CompressedImage.h:59): device tile encode + host entropy stage -> bytes."""
         rgb = np.ascontiguousarray(rgb, np.uint8)
@@ -465,6 +473,16 @@ class CompressionContext:
 
     def encode_image_device(self, d_rgb, width, height, quant=None):
         return self.encode_images_device([d_rgb], width, height, quant)[0]
+
+    def records_to_container_device(self, d_counts, d_choices, width, height, quant=None, stream=0):
+        """mpc_records_to_container_device: whole-frame records in device memory -> container bytes."""
+        qp = None
+        if quant is not None:
+            quant = np.ascontiguousarray(quant, np.float64).reshape(3, self.K)
+            qp = quant.ctypes.data_as(_dp)
+        out, n = _u8p(), C.c_size_t(0)
+        _check(self.L.mpc_records_to_container_device(self.h, d_counts, d_choices, width, height, qp, stream or None, C.byref(out), C.byref(n)))
+        return _take_bytes(self.L, out, n)
 
     def calc_mp(self, channel, vectors, quant_k=None):
         """matching::CalcMPDynamic (MatchingPursuit.h:22) on the device for vectors[n,64].

@@ -136,35 +136,40 @@ int launch_decode(const DictDevice& dict, const DecodeParams& p, void* stream);
 constexpr int kMaxPairs = 32;           // (tile-channel, unlocked block other than DetailBasis[0]) pairs a tile-channel can hold (< K)
 
 struct PursuitArgs {
-    // dictionary of this channel
+    // dictionary
     const double* base;              // [512][64]
-    const double* detail;            // this channel's [detail_rows][64]
+    const double* detail[3];         // per channel [detail_rows][64]
     const uint16_t* base_tiles;      // [kBaseFilterTiles][2048], k order 1 (host_dictionary.h: filter_tiles)
-    const uint16_t* block_tiles;     // this channel's [num_base][kBlockFilterTiles][2048], k order 1
-    const float* gram;               // this channel's [num_base + detail_rows][gram_stride]
+    const uint16_t* block_tiles[3];  // per channel [num_base][kBlockFilterTiles][2048], k order 1
+    const float* gram[3];            // per channel [num_base + detail_rows][gram_stride]
     long long gram_stride;           // num_base * 64
     const int32_t* block_rows;
     const int32_t* block_row_off;
-    const double* quant;             // this channel's [K] (device)
-    int K, channel, num_base, rows0;
-    // input: tile mode (rgb) or vector mode (vec_in != nullptr: CalcMPDynamic on caller vectors of this channel)
+    const double* quant;             // [3][K] (device)
+    int K, num_base, rows0;
+    // One launch covers all channels: workgroups [0, wg[0]) take channel 0's units, the next wg[1] channel 1's, then channel 2's
+    // (a workgroup's LDS holds DetailBasis[0] of ONE channel).  Vector mode: only `vec_channel` has workgroups.
+    int wg[3];
+    // input: tile mode (rgb) or vector mode (vec_in != nullptr: CalcMPDynamic on caller vectors of channel vec_channel)
     const uint8_t* rgb;
     int width, height;
     long long row_stride, frame_stride;
     int tile_row_begin, tile_rows, tiles_x;
     const double* vec_in;
-    long long n_tc;                  // tile-channels of this channel (tiles of the stripe x frames, or vectors)
+    int vec_channel;
+    long long n_tc;                  // tile-channels per channel (tiles of the stripe x frames, or vectors)
     int n_units;                     // ceil(n_tc / 16)
-    unsigned* queue;                 // next unit (zero before the launch)
-    // per-wave scratch for the pairs (sizes: pursuit_scratch_*)
-    float* pair_p;
-    unsigned* pair_meta;
-    float* pair_e;
+    unsigned* queue;                 // [3] next unit of each channel (zero before the launch)
+    // per-wave scratch for the pairs, per channel (sizes: pursuit_scratch_*)
+    float* pair_p[3];
+    unsigned* pair_meta[3];
+    float* pair_e[3];
     Outputs out;
+    unsigned long long* stats;       // [2] += executed MFMA instructions, tile-channel-steps (one atomic per wave at exit); may be null
     unsigned long long* debug;       // diagnostic builds (-DMPC_STAMPS) only: 24 phase-cycle / event counters; else null
 };
 
-int launch_pursuit(const PursuitArgs& args, int workgroups, void* stream);
+int launch_pursuit(const PursuitArgs& args, void* stream);       // grid = wg[0] + wg[1] + wg[2] workgroups
 size_t pursuit_scratch_floats(int workgroups);
 size_t pursuit_scratch_meta(int workgroups);
 size_t pursuit_scratch_bounds(int workgroups);

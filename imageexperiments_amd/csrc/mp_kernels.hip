@@ -1374,15 +1374,15 @@ __global__ __launch_bounds__(256) void mp_histogram_kernel(const HistParams p, i
     const long long t1 = (t0 + per < p.tiles) ? t0 + per : p.tiles;
     if (job == 0) {
         for (long long o = t0 * 3 + threadIdx.x; o < t1 * 3; o += blockDim.x)
-            atomicAdd(&h0[p.counts[o] & (kHistBins - 1)], 1u);
+            if (p.counts[o] < kHistBins) atomicAdd(&h0[p.counts[o]], 1u);
     } else {
         const int ch = (job - 1) / p.K, i = (job - 1) - ch * p.K;
         for (long long t = t0 + threadIdx.x; t < t1; t += blockDim.x) {
             const long long o = t * 3 + ch;
             if (p.counts[o] > i) {
                 const uint32_t rec = p.choices[o * p.K + i];
-                atomicAdd(&h0[rec & 0xFFFFu & (kHistBins - 1)], 1u);
-                atomicAdd(&h1[(rec >> 16) & (kHistBins - 1)], 1u);
+                if ((rec & 0xFFFFu) < (unsigned)kHistBins) atomicAdd(&h0[rec & 0xFFFFu], 1u);       // symbols beyond the table are
+                if ((rec >> 16) < (unsigned)kHistBins) atomicAdd(&h1[rec >> 16], 1u);               // not counted (sharding.py agrees)
             }
         }
     }

@@ -241,9 +241,17 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
     __shared__ uint4 s_tiles[kTilesLds * 256];                      // [tile][operand q][lane], 4 KiB per tile
     __shared__ int s_rows[512], s_rowoff[512];                      // block_rows / block_row_off
     __shared__ unsigned s_touch[64 * kWaves];                       // landing zone of the cache-touch loads (never read)
+    // this workgroup's channel and its index among that channel's workgroups
+    const int ch = (int)blockIdx.x < a.wg[0] ? 0 : ((int)blockIdx.x < a.wg[0] + a.wg[1] ? 1 : 2);
+    const int wg_local = (int)blockIdx.x - (ch == 0 ? 0 : (ch == 1 ? a.wg[0] : a.wg[0] + a.wg[1]));
+    const double* const detail = ch == 0 ? a.detail[0] : (ch == 1 ? a.detail[1] : a.detail[2]);
+    const uint16_t* const block_tiles = ch == 0 ? a.block_tiles[0] : (ch == 1 ? a.block_tiles[1] : a.block_tiles[2]);
+    const float* const gram = ch == 0 ? a.gram[0] : (ch == 1 ? a.gram[1] : a.gram[2]);
+    const double* const quant = a.quant + ch * a.K;
+    unsigned* const queue = a.queue + ch;
     {
         const uint4* src_base = reinterpret_cast<const uint4*>(a.base_tiles);
-        const uint4* src_blk0 = reinterpret_cast<const uint4*>(a.block_tiles);      // block 0 = the first four tiles
+        const uint4* src_blk0 = reinterpret_cast<const uint4*>(block_tiles);        // block 0 = the first four tiles
         for (int i = threadIdx.x; i < kTilesLds * 256; i += 64 * kWaves)
             s_tiles[i] = i < kBaseFilterTiles * 256 ? src_base[i] : src_blk0[i - kBaseFilterTiles * 256];
         for (int i = threadIdx.x; i < 512; i += 64 * kWaves) {
@@ -256,13 +264,14 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int slot = lane & 15, h = lane >> 4;
     const int pix0 = 16 * pos_of(h);                                // first of this lane's 16 consecutive pixels
-    const long long wave_global = (long long)blockIdx.x * kWaves + wave;
-    float* const my_p = a.pair_p + wave_global * (kGroups * 16 * kMaxPairs * 64);
-    unsigned* const my_meta = a.pair_meta + wave_global * (kGroups * 16 * kMaxPairs * 2);
-    float* const my_e = a.pair_e + wave_global * (kGroups * 16 * kMaxPairs);
+    const long long wave_global = (long long)wg_local * kWaves + wave;
+    float* const my_p = (ch == 0 ? a.pair_p[0] : (ch == 1 ? a.pair_p[1] : a.pair_p[2])) + wave_global * (kGroups * 16 * kMaxPairs * 64);
+    unsigned* const my_meta = (ch == 0 ? a.pair_meta[0] : (ch == 1 ? a.pair_meta[1] : a.pair_meta[2])) + wave_global * (kGroups * 16 * kMaxPairs * 2);
+    float* const my_e = (ch == 0 ? a.pair_e[0] : (ch == 1 ? a.pair_e[1] : a.pair_e[2])) + wave_global * (kGroups * 16 * kMaxPairs);
     unsigned* const my_touch = s_touch + 64 * wave;
-    const int K = a.K, ch = a.channel;
+    const int K = a.K;
 
+    unsigned n_mfma = 0, n_steps = 0;                               // executed MFMA instructions / tile-channel-steps of this wave
     int unit[kGroups], step[kGroups];
     double r[kGroups][16];
     TileChannel tc[kGroups];
@@ -296,7 +305,7 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
             constexpr int g = decltype(gc)::value;
             if (unit[g] >= 0 || queue_empty) return;
             int u = 0;
-            if (lane == 0) u = (int)atomicAdd(a.queue, 1u);
+            if (lane == 0) u = (int)atomicAdd(queue, 1u);
             u = __builtin_amdgcn_readfirstlane(u);
             if (u >= a.n_units) { queue_empty = true; return; }
             unit[g] = u;
@@ -340,6 +349,7 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
 #pragma unroll
         for (int g = 0; g < kGroups; ++g) any_unit = any_unit || unit[g] >= 0;
         if (!any_unit) break;
+        static_for<kGroups>([&](auto gc) { n_steps += (unsigned)__popcll(__ballot(unit[decltype(gc)::value] >= 0 && tc[decltype(gc)::value].live && h == 0)); });
         STAMP(0)
         COUNT(12, 1)
         static_for<kGroups>([&](auto gc) { COUNT(16, __popcll(__ballot(tc[decltype(gc)::value].live && unit[decltype(gc)::value] >= 0))) });
@@ -356,7 +366,7 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
             info0[g] = tc[g].packed(0);
             const long long pi = (long long)(g * 16 + slot) * kMaxPairs;
             const float4* pp = reinterpret_cast<const float4*>(my_p + pi * 64 + 4 * h);
-            const float4* gp = reinterpret_cast<const float4*>(a.gram + (upd0[g] ? (long long)tc[g].sel_g * a.gram_stride + (int)(info0[g] & 511u) * 64 : 0) + 4 * h);
+            const float4* gp = reinterpret_cast<const float4*>(gram + (upd0[g] ? (long long)tc[g].sel_g * a.gram_stride + (int)(info0[g] & 511u) * 64 : 0) + 4 * h);
 #pragma unroll
             for (int t = 0; t < 4; ++t) { pv0[g][t] = pp[4 * t]; gv0[g][t] = gp[4 * t]; }
             E0[g] = my_e[pi];
@@ -460,7 +470,7 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
                 info[g] = p < 4 ? tc[g].packed(p) : (my_meta[2 * pi] & 0xFFFFu);
                 upd[g] = on[g] && tc[g].coeff != 0.0;
                 const float4* pp = reinterpret_cast<const float4*>(my_p + pi * 64 + 4 * h);
-                const float4* gp = reinterpret_cast<const float4*>(a.gram + (upd[g] ? (long long)tc[g].sel_g * a.gram_stride + (int)(info[g] & 511u) * 64 : 0) + 4 * h);
+                const float4* gp = reinterpret_cast<const float4*>(gram + (upd[g] ? (long long)tc[g].sel_g * a.gram_stride + (int)(info[g] & 511u) * 64 : 0) + 4 * h);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) { pv[g][t] = pp[4 * t]; gv[g][t] = gp[4 * t]; }
                 E[g] = my_e[pi];
@@ -490,7 +500,8 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
                 const int src = __builtin_ctzll(pend);
                 pend &= pend - 1;
                 const int blk = __builtin_amdgcn_readlane((int)(fresh_info & 511u), src);
-                const uint4* tiles = reinterpret_cast<const uint4*>(a.block_tiles) + (long long)blk * (kBlockFilterTiles * 256) + lane;
+                n_mfma += 6 * kBlockFilterTiles;
+                const uint4* tiles = reinterpret_cast<const uint4*>(block_tiles) + (long long)blk * (kBlockFilterTiles * 256) + lane;
 #pragma unroll
                 for (int t2 = 0; t2 < kBlockFilterTiles; t2 += 2) {
                     uint4 av[2][4];
@@ -524,6 +535,7 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
         bool any0 = false;
 #pragma unroll
         for (int g = 0; g < kGroups; ++g) any0 = any0 || (unit[g] >= 0 && __ballot(tc[g].live && tc[g].has0) != 0);
+        n_mfma += 6 * kGroups * (kBaseFilterTiles + (any0 ? kBlockFilterTiles : 0));
         {
             uint4 ta[4], tbuf[4];
             f32x4 acc[kGroups], prev[kGroups];
@@ -624,6 +636,7 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
             uint4 cur[4], nxt[4];
             lds_tile(cur, 0);
             const int last = any0 ? kTilesLds : kBaseFilterTiles;
+            static_for<kGroups>([&](auto gc) { n_mfma += pass2[decltype(gc)::value] ? 6 * last : 0; });
 #pragma unroll 1
             for (int t = 0; t < last; ++t) {
                 lds_tile(nxt, t + 1 < last ? t + 1 : t);
@@ -688,13 +701,13 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
             constexpr int g = decltype(gc)::value;
             const int seg = code >> 16, row = code & 2047;
             if (seg == 0) { ptr = a.base + (long long)row * N; idx = row; sel = row; }
-            else if (seg == 1) { ptr = a.detail + (long long)row * N; idx = tc[g].off0 + row; sel = a.num_base + row; }
+            else if (seg == 1) { ptr = detail + (long long)row * N; idx = tc[g].off0 + row; sel = a.num_base + row; }
             else {
                 const int p = (code >> 11) & 31;
                 const long long pi = (long long)(g * 16 + slot) * kMaxPairs + p;
                 const unsigned meta = my_meta[2 * pi];
                 const int drow = s_rowoff[meta & 511u] + row;
-                ptr = a.detail + (long long)drow * N;
+                ptr = detail + (long long)drow * N;
                 idx = (int)(meta >> 16) + row;
                 sel = a.num_base + drow;
             }
@@ -782,7 +795,7 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
 #pragma unroll
         for (int g = 0; g < kGroups; ++g) {
             const int sg = (unit[g] >= 0 && tc[g].live && best_idx[g] >= 0) ? best_sel[g] : 0;      // Gram row -> the row itself
-            load16(xrow[g], (sg < a.num_base ? a.base + (long long)sg * N : a.detail + (long long)(sg - a.num_base) * N) + pix0);
+            load16(xrow[g], (sg < a.num_base ? a.base + (long long)sg * N : detail + (long long)(sg - a.num_base) * N) + pix0);
         }
         // delta / zig-zag, quantise, record, unlock, termination (MatchingPursuit.cpp:50-71)
         bool ended[kGroups];
@@ -803,7 +816,7 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
                 const int id = best_idx[g];
                 const unsigned delta = step[g] > 0 ? (((unsigned)(id - s.prev_id) << 1) ^ (unsigned)((id - s.prev_id) >> 31)) : (unsigned)id;
                 s.prev_id = id;
-                const double qstep = a.quant[step[g]];
+                const double qstep = quant[step[g]];
                 const int q = (int)__builtin_round(best_val[g] / qstep);
                 const unsigned zz = ((unsigned)q << 1) ^ (unsigned)(q >> 31);
                 record = (delta & 0xFFFFu) | ((zz & 0xFFFFu) << 16);
@@ -873,7 +886,7 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
                 const int np = s.npairs < 4 ? s.npairs : 4;
                 for (int p = 0; p < np; ++p) {
                     if (p == s.fresh) continue;
-                    const float* line = a.gram + (long long)s.sel_g * a.gram_stride + (int)(s.packed(p) & 511u) * 64 + 32 * h;
+                    const float* line = gram + (long long)s.sel_g * a.gram_stride + (int)(s.packed(p) & 511u) * 64 + 32 * h;
                     __builtin_amdgcn_global_load_lds(line, my_touch, 4, 0, 0);
                 }
             }
@@ -882,7 +895,7 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
                 const int src = __builtin_ctzll(pend);
                 pend &= pend - 1;
                 const int blk = __builtin_amdgcn_readlane((int)(s.packed(s.fresh < 4 ? s.fresh : 0) & 511u), src);
-                const uint16_t* tiles = a.block_tiles + (long long)blk * (kBlockFilterTiles * 2048) + 64 * lane;
+                const uint16_t* tiles = block_tiles + (long long)blk * (kBlockFilterTiles * 2048) + 64 * lane;
                 __builtin_amdgcn_global_load_lds(tiles, my_touch, 4, 0, 0);
                 __builtin_amdgcn_global_load_lds(tiles + 4096, my_touch, 4, 0, 0);
             }
@@ -891,6 +904,10 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
             if (!__ballot(s.live)) unit[g] = -1;
         });
         STAMP(11)
+    }
+    if (lane == 0 && a.stats) {
+        atomicAdd(a.stats + 0, (unsigned long long)n_mfma);
+        atomicAdd(a.stats + 1, (unsigned long long)n_steps);
     }
 #ifdef MPC_STAMPS
     if (lane == 0 && a.debug)
@@ -960,9 +977,10 @@ size_t pursuit_scratch_meta(int workgroups) { return (size_t)workgroups * kWaves
 size_t pursuit_scratch_bounds(int workgroups) { return (size_t)workgroups * kWaves * kGroups * 16 * kMaxPairs; }
 int pursuit_units_per_workgroup() { return kWaves * kGroups; }
 
-int launch_pursuit(const PursuitArgs& args, int workgroups, void* stream)
+int launch_pursuit(const PursuitArgs& args, void* stream)
 {
-    if (workgroups < 1) workgroups = 1;
+    const int workgroups = args.wg[0] + args.wg[1] + args.wg[2];
+    if (workgroups < 1) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(mp_pursuit_kernel, dim3((unsigned)workgroups), dim3(64 * kWaves), 0, static_cast<hipStream_t>(stream), args);
     return (int)hipGetLastError();
 }

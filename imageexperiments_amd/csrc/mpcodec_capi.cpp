@@ -86,26 +86,24 @@ struct DeviceDict {
     uint8_t* d_shadow = nullptr;      // [3][detail_rows]
     float* d_gram = nullptr;          // [3][num_base + detail_rows][num_base * 64]
     std::mutex launch_lock;           // one enqueue sequence at a time
-    hipStream_t chan[3] = {};
-    hipEvent_t fork = nullptr, done[3] = {};
+    hipEvent_t done[1] = {};          // recorded behind every launch: the next one (any stream) waits for it
     int workgroups = 0;               // scratch is sized for this many workgroups per launch
     float* pair_p[3] = {};
     unsigned* pair_meta[3] = {};
     float* pair_e[3] = {};
     unsigned* queues = nullptr;       // [3]
+    unsigned long long* stats = nullptr;   // [2]: MFMA instructions, tile-channel-steps executed by the persistent kernel since the last reset
     ~DeviceDict() {
         if (device < 0) return;
         (void)hipSetDevice(device);
         (void)hipDeviceSynchronize();
         (void)hipFree(d_base); (void)hipFree(d_detail); (void)hipFree(d_rows); (void)hipFree(d_rowoff);
         (void)hipFree(d_base_f32); (void)hipFree(d_detail_f32); (void)hipFree(d_base_t1); (void)hipFree(d_detail_t1);
-        (void)hipFree(d_shadow); (void)hipFree(d_gram); (void)hipFree(queues);
+        (void)hipFree(d_shadow); (void)hipFree(d_gram); (void)hipFree(queues); (void)hipFree(stats);
         for (int ch = 0; ch < 3; ++ch) {
             (void)hipFree(pair_p[ch]); (void)hipFree(pair_meta[ch]); (void)hipFree(pair_e[ch]);
-            if (chan[ch]) (void)hipStreamDestroy(chan[ch]);
-            if (done[ch]) (void)hipEventDestroy(done[ch]);
         }
-        if (fork) (void)hipEventDestroy(fork);
+        if (done[0]) (void)hipEventDestroy(done[0]);
     }
 };
 
@@ -164,12 +162,13 @@ hipError_t acquire_device_dict(int device, const mpc::Dictionary& dict, std::sha
                                                      static_cast<int>(n_sel), stride, nullptr));
     // persistent kernel: streams, events, queue words, per-wave scratch for one workgroup per CU
     d->workgroups = d->num_cus > 0 ? d->num_cus : 1;
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&d->fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&d->done[0], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventRecord(d->done[0], nullptr);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d->queues), 64);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d->stats), 2 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(d->stats, 0, 2 * sizeof(unsigned long long));
     for (int ch = 0; ch < 3 && e == hipSuccess; ++ch) {
-        e = hipStreamCreateWithFlags(&d->chan[ch], hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&d->done[ch], hipEventDisableTiming);
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d->pair_p[ch]), sizeof(float) * mpc::pursuit_scratch_floats(d->workgroups));
+        e = hipMalloc(reinterpret_cast<void**>(&d->pair_p[ch]), sizeof(float) * mpc::pursuit_scratch_floats(d->workgroups));
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d->pair_meta[ch]), sizeof(unsigned) * mpc::pursuit_scratch_meta(d->workgroups));
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d->pair_e[ch]), sizeof(float) * mpc::pursuit_scratch_bounds(d->workgroups));
     }
@@ -338,99 +337,99 @@ constexpr int kBaseParts = 8;
 constexpr int kRowParts = 4;
 
 
-// The persistent path (mp_pursuit.hip): one launch per channel on the device's three channel streams, forked from and joined
-// to the caller's stream with events.  No host synchronisation, no allocation.
+// The persistent path (mp_pursuit.hip): ONE launch on the caller's stream runs all K steps of every tile-channel; its
+// workgroups are split over the channels (a workgroup's LDS holds one channel's DetailBasis[0]).  No host synchronisation,
+// no allocation: graph-capturable.  Launches of one process are serialised on the device by a lock-ordered event chain,
+// because they share the per-device scratch and queue words.
 mpc_status run_persistent(mpc_context* c, const mpc::FrameInput& in, const mpc::Outputs& out, const double* d_quant,
                           long long total_tc, void* stream) {
     DeviceDict& d = *c->dd;
-    hipStream_t caller = static_cast<hipStream_t>(stream);
+    hipStream_t s = static_cast<hipStream_t>(stream);
     const bool vec = in.vec_in != nullptr;
     const long long n_tc = vec ? total_tc : total_tc / 3;
     const long long n_units = (n_tc + 15) / 16;
     if (n_units >= (1LL << 31)) return fail(MPC_ERR_ARGUMENT, "batch too large");
     const int per_wg = mpc::pursuit_units_per_workgroup();
     int workgroups = static_cast<int>(std::min<long long>((n_units + per_wg - 1) / per_wg, d.workgroups));
-    // One workgroup fits a CU (its LDS holds the dictionary), and the three channel launches run side by side.  A small frame
-    // (less than three rounds of the machine in all) gets a third of the CUs per channel, so that no channel waits for CUs
-    // another one holds; a large one is dominated by the luma launch, which then wants every CU.
+    // One workgroup fits a CU (its LDS holds the dictionary).  The luma workgroups come first in the grid and get the CUs
+    // first; chroma workgroups take over as they retire.  A small frame (less than three rounds of the machine in all) gets a
+    // third of the CUs per channel instead, so that all three run side by side from the start.
     if (!vec && 3 * n_units < 3LL * d.workgroups * per_wg) workgroups = std::min(workgroups, std::max(1, d.workgroups / 3));
     const int forced = env_int("MPC_WORKGROUPS", 0);
     if (forced > 0) workgroups = std::min(forced, d.workgroups);
     std::lock_guard<std::mutex> hold(d.launch_lock);
-    HIP_TRY(hipEventRecord(d.fork, caller));
+    HIP_TRY(hipStreamWaitEvent(s, d.done[0], 0));             // the previous launch of this process (any stream) has drained
+    HIP_TRY(hipMemsetAsync(d.queues, 0, 3 * sizeof(unsigned), s));
     const long long n_sel = d.num_base + d.detail_rows, stride = static_cast<long long>(d.num_base) * 64;
+    mpc::PursuitArgs a{};
+    a.base = d.d_base;
+    a.base_tiles = d.d_base_t1;
     for (int ch = 0; ch < 3; ++ch) {
-        if (vec && ch != in.vec_channel) continue;
-        hipStream_t s = d.chan[ch];
-        HIP_TRY(hipStreamWaitEvent(s, d.fork, 0));
-        HIP_TRY(hipMemsetAsync(d.queues + ch, 0, sizeof(unsigned), s));
-        mpc::PursuitArgs a{};
-        a.base = d.d_base;
-        a.detail = d.d_detail + static_cast<size_t>(ch) * d.detail_rows * mpc::kTileN;
-        a.base_tiles = d.d_base_t1;
-        a.block_tiles = d.d_detail_t1 + static_cast<size_t>(ch) * d.num_base * mpc::kBlockFilterTiles * mpc::kFilterTileHalves;
-        a.gram = d.d_gram + static_cast<size_t>(ch) * n_sel * stride;
-        a.gram_stride = stride;
-        a.block_rows = d.d_rows;
-        a.block_row_off = d.d_rowoff;
-        a.quant = d_quant + static_cast<size_t>(ch) * c->K;
-        a.K = c->K;
-        a.channel = ch;
-        a.num_base = d.num_base;
-        a.rows0 = c->dict.block_rows.empty() ? 0 : c->dict.block_rows[0];
-        a.rgb = in.rgb;
-        a.width = in.width;
-        a.height = in.height;
-        a.row_stride = in.row_stride;
-        a.frame_stride = in.frame_stride;
-        a.tile_row_begin = in.tile_row_begin;
-        a.tile_rows = in.tile_rows;
-        a.tiles_x = in.tiles_x;
-        a.vec_in = in.vec_in;
-        a.n_tc = n_tc;
-        a.n_units = static_cast<int>(n_units);
-        a.queue = d.queues + ch;
-        a.pair_p = d.pair_p[ch];
-        a.pair_meta = d.pair_meta[ch];
-        a.pair_e = d.pair_e[ch];
-        a.out = out;
-        hipEvent_t* ev = nullptr;
-        if (c->timing) {
-            const size_t need = c->timing_used + 2;
-            while (c->timing_events.size() < need) {
-                hipEvent_t e;
-                if (hipEventCreate(&e) != hipSuccess) return fail(MPC_ERR_HIP, "hipEventCreate failed");
-                c->timing_events.push_back(e);
-            }
-            ev = c->timing_events.data() + c->timing_used;
-            c->timing_used = need;
-            HIP_TRY(hipEventRecord(ev[0], s));
-        }
-#ifdef MPC_STAMPS
-        static unsigned long long* d_debug = nullptr;
-        if (!d_debug) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_debug), 24 * sizeof(unsigned long long)));
-        HIP_TRY(hipMemsetAsync(d_debug, 0, 24 * sizeof(unsigned long long), s));
-        a.debug = d_debug;
-#endif
-        const int err = mpc::launch_pursuit(a, workgroups, s);
-        if (err != 0) return fail(MPC_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(err)));
-#ifdef MPC_STAMPS
-        {
-            unsigned long long hst[24];
-            HIP_TRY(hipStreamSynchronize(s));
-            HIP_TRY(hipMemcpy(hst, d_debug, sizeof hst, hipMemcpyDeviceToHost));
-            unsigned long long tot = 0;
-            for (int i = 0; i < 12; ++i) tot += hst[i];
-            std::fprintf(stderr, "[stamps ch%d wg%d] wave-steps %llu live-lanes/step %.1f pass2-groups %llu rounds %llu exhaustive %llu | cycles/wave-step:",
-                         ch, workgroups, hst[12], hst[12] ? (double)hst[16] / hst[12] / 4.0 : 0.0, hst[13], hst[14], hst[15]);
-            for (int i = 0; i < 12; ++i) std::fprintf(stderr, " %d:%.0f", i, hst[12] ? (double)hst[i] / hst[12] : 0.0);
-            std::fprintf(stderr, " total %.0f\n", hst[12] ? (double)tot / hst[12] : 0.0);
-        }
-#endif
-        if (ev) HIP_TRY(hipEventRecord(ev[1], s));
-        HIP_TRY(hipEventRecord(d.done[ch], s));
-        HIP_TRY(hipStreamWaitEvent(caller, d.done[ch], 0));
+        a.detail[ch] = d.d_detail + static_cast<size_t>(ch) * d.detail_rows * mpc::kTileN;
+        a.block_tiles[ch] = d.d_detail_t1 + static_cast<size_t>(ch) * d.num_base * mpc::kBlockFilterTiles * mpc::kFilterTileHalves;
+        a.gram[ch] = d.d_gram + static_cast<size_t>(ch) * n_sel * stride;
+        a.pair_p[ch] = d.pair_p[ch];
+        a.pair_meta[ch] = d.pair_meta[ch];
+        a.pair_e[ch] = d.pair_e[ch];
+        a.wg[ch] = vec ? (ch == in.vec_channel ? workgroups : 0) : workgroups;
     }
+    a.gram_stride = stride;
+    a.block_rows = d.d_rows;
+    a.block_row_off = d.d_rowoff;
+    a.quant = d_quant;
+    a.K = c->K;
+    a.num_base = d.num_base;
+    a.rows0 = c->dict.block_rows.empty() ? 0 : c->dict.block_rows[0];
+    a.rgb = in.rgb;
+    a.width = in.width;
+    a.height = in.height;
+    a.row_stride = in.row_stride;
+    a.frame_stride = in.frame_stride;
+    a.tile_row_begin = in.tile_row_begin;
+    a.tile_rows = in.tile_rows;
+    a.tiles_x = in.tiles_x;
+    a.vec_in = in.vec_in;
+    a.vec_channel = in.vec_channel;
+    a.n_tc = n_tc;
+    a.n_units = static_cast<int>(n_units);
+    a.queue = d.queues;
+    a.out = out;
+    a.stats = d.stats;
+    hipEvent_t* ev = nullptr;
+    if (c->timing) {
+        const size_t need = c->timing_used + 2;
+        while (c->timing_events.size() < need) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return fail(MPC_ERR_HIP, "hipEventCreate failed");
+            c->timing_events.push_back(e);
+        }
+        ev = c->timing_events.data() + c->timing_used;
+        c->timing_used = need;
+        HIP_TRY(hipEventRecord(ev[0], s));
+    }
+#ifdef MPC_STAMPS
+    static unsigned long long* d_debug = nullptr;
+    if (!d_debug) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_debug), 24 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(d_debug, 0, 24 * sizeof(unsigned long long), s));
+    a.debug = d_debug;
+#endif
+    const int err = mpc::launch_pursuit(a, s);
+    if (err != 0) return fail(MPC_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(err)));
+    if (ev) HIP_TRY(hipEventRecord(ev[1], s));
+    HIP_TRY(hipEventRecord(d.done[0], s));
+#ifdef MPC_STAMPS
+    {
+        unsigned long long hst[24];
+        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipMemcpy(hst, d_debug, sizeof hst, hipMemcpyDeviceToHost));
+        unsigned long long tot = 0;
+        for (int i = 0; i < 12; ++i) tot += hst[i];
+        std::fprintf(stderr, "[stamps wg%d x3] wave-steps %llu live-lanes/step %.1f pass2-groups %llu rounds %llu exhaustive %llu | cycles/wave-step:",
+                     workgroups, hst[12], hst[12] ? (double)hst[16] / hst[12] / 4.0 : 0.0, hst[13], hst[14], hst[15]);
+        for (int i = 0; i < 12; ++i) std::fprintf(stderr, " %d:%.0f", i, hst[12] ? (double)hst[i] / hst[12] : 0.0);
+        std::fprintf(stderr, " total %.0f\n", hst[12] ? (double)tot / hst[12] : 0.0);
+    }
+#endif
     return MPC_OK;
 }
 
@@ -799,6 +798,8 @@ void mpc_kernel_timing_enable(mpc_context* c, int on) {
     c->timing_used = 0;
     if (c->timing && c->device >= 0) {
         (void)hipSetDevice(c->device);
+        (void)hipDeviceSynchronize();
+        if (c->dd) (void)hipMemset(c->dd->stats, 0, 2 * sizeof(unsigned long long));
         if (!c->timing_ref) (void)hipEventCreate(&c->timing_ref);
         (void)hipDeviceSynchronize();
         (void)hipEventRecord(c->timing_ref, nullptr);
@@ -839,6 +840,19 @@ mpc_status mpc_kernel_timing_read(mpc_context* c, double* total_ms, long long* l
     *launches = static_cast<long long>(c->timing_used / 2);
     if (busy_ms) *busy_ms = busy;
     c->timing_used = 0;
+    return MPC_OK;
+}
+
+mpc_status mpc_kernel_counters_read(mpc_context* c, unsigned long long* mfma_instructions, unsigned long long* tile_channel_steps) {
+    if (!c || !mfma_instructions || !tile_channel_steps) return fail(MPC_ERR_ARGUMENT, "null argument");
+    if (c->device < 0) return fail(MPC_ERR_NO_DEVICE, "context was created without a device");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipDeviceSynchronize());
+    unsigned long long v[2] = {0, 0};
+    HIP_TRY(hipMemcpy(v, c->dd->stats, sizeof v, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(c->dd->stats, 0, sizeof v));
+    *mfma_instructions = v[0];
+    *tile_channel_steps = v[1];
     return MPC_OK;
 }
 
@@ -1160,6 +1174,72 @@ static mpc_status encode_sequence(mpc_context* c, const uint8_t* const* frames, 
         for (int f = 0; f < n_frames; ++f) { std::free(bytes[f]); bytes[f] = nullptr; nbytes[f] = 0; }
     }
     return st;
+}
+
+// The second half of encodeImage for records that are already on the device in whole-frame order (the owner of a frame in
+// the multi-GPU path, after the stripe exchange): stream assembly on `stream`, the live symbols to the host, entropy stage.
+mpc_status mpc_records_to_container_device(mpc_context* c, const uint16_t* d_counts, const mpc_basis_choice* d_choices, int width,
+                                           int height, const double* quant, void* stream, uint8_t** bytes, size_t* nbytes) {
+    return guarded([&]() -> mpc_status {
+    if (!c || !d_counts || !d_choices || !bytes || !nbytes) return fail(MPC_ERR_ARGUMENT, "null argument");
+    if (c->device < 0) return fail(MPC_ERR_NO_DEVICE, "context was created without a device");
+    if (width < 1 || height < 1) return fail(MPC_ERR_ARGUMENT, "bad geometry");
+    const size_t tiles = static_cast<size_t>((width + 7) / 8) * ((height + 7) / 8), n_tc = tiles * 3;
+    const int K = c->K;
+    std::lock_guard<std::recursive_mutex> one_host_call(c->host_calls);
+    HIP_TRY(hipSetDevice(c->device));
+    auto up = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
+    const size_t counts_bytes = up(sizeof(uint16_t) * n_tc), off_bytes = up(sizeof(unsigned long long) * (6 * static_cast<size_t>(K) + 1));
+    const size_t symbols_bytes = up(sizeof(uint16_t) * 2 * n_tc * K);
+    const size_t live_bytes = up(sizeof(unsigned) * mpc::stream_workspace_words(static_cast<long long>(tiles), K));
+    const size_t sizes_bytes = up(sizeof(unsigned) * 3 * K), dc_bytes = up(sizeof(uint16_t) * n_tc);
+    const size_t host_need = counts_bytes + off_bytes + symbols_bytes, dev_need = live_bytes + sizes_bytes + off_bytes + symbols_bytes + dc_bytes;
+    if (host_need > c->host_stage_bytes) {
+        if (c->host_stage) (void)hipHostFree(c->host_stage);
+        c->host_stage = nullptr;
+        c->host_stage_bytes = 0;
+        const hipError_t e = hipHostMalloc(&c->host_stage, host_need, hipHostMallocDefault);
+        if (e != hipSuccess) return fail(MPC_ERR_ALLOC, "pinned staging of %zu bytes: %s", host_need, hipGetErrorString(e));
+        c->host_stage_bytes = host_need;
+    }
+    if (dev_need > c->stage_bytes) {
+        HIP_TRY(hipDeviceSynchronize());
+        if (c->stage) (void)hipFree(c->stage);
+        c->stage = nullptr;
+        c->stage_bytes = 0;
+        const hipError_t e = hipMalloc(&c->stage, dev_need);
+        if (e != hipSuccess) return fail(MPC_ERR_ALLOC, "device staging of %zu bytes: %s", dev_need, hipGetErrorString(e));
+        c->stage_bytes = dev_need;
+    }
+    char* dbase = static_cast<char*>(c->stage);
+    char* hbase = static_cast<char*>(c->host_stage);
+    mpc::StreamArgs sa{};
+    sa.counts = d_counts;
+    sa.choices = reinterpret_cast<const uint32_t*>(d_choices);
+    sa.tiles = static_cast<long long>(tiles);
+    sa.K = K;
+    sa.block_live = reinterpret_cast<unsigned*>(dbase);
+    sa.sizes = reinterpret_cast<unsigned*>(dbase + live_bytes);
+    sa.stream_off = reinterpret_cast<unsigned long long*>(dbase + live_bytes + sizes_bytes);
+    sa.symbols = reinterpret_cast<uint16_t*>(dbase + live_bytes + sizes_bytes + off_bytes);
+    sa.dc_tmp = reinterpret_cast<uint16_t*>(dbase + live_bytes + sizes_bytes + off_bytes + symbols_bytes);
+    uint16_t* counts = reinterpret_cast<uint16_t*>(hbase);
+    unsigned long long* off = reinterpret_cast<unsigned long long*>(hbase + counts_bytes);
+    uint16_t* symbols = reinterpret_cast<uint16_t*>(hbase + counts_bytes + off_bytes);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int err = mpc::launch_stream_assembly(sa, s);
+    if (err != 0) return fail(MPC_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(err)));
+    const size_t n_off = 6 * static_cast<size_t>(K) + 1;
+    HIP_TRY(hipMemcpyAsync(off, sa.stream_off, sizeof(unsigned long long) * n_off, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(counts, d_counts, sizeof(uint16_t) * n_tc, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const unsigned long long total = off[n_off - 1];
+    if (total > 2ULL * n_tc * static_cast<unsigned long long>(K)) return fail(MPC_ERR_HIP, "stream assembly returned an impossible size");
+    if (total) HIP_TRY(hipMemcpyAsync(symbols, sa.symbols, sizeof(uint16_t) * total, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    *bytes = mpc::encode_symbol_streams_malloc(width, height, K, c->block_size, quant ? quant : c->quant.data(), counts, symbols, off, nbytes);
+    return *bytes ? MPC_OK : fail(MPC_ERR_ALLOC, "out of memory");
+    });
 }
 
 mpc_status mpc_encode_images(mpc_context* c, const uint8_t* const* rgb_frames, int n_frames, int width, int height,

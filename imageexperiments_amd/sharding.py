@@ -1,11 +1,18 @@
 """Row-stripe sharding of frames over the GPUs of one node (one process per GPU, torch.distributed).
 
-The tile encode is embarrassingly parallel: rank r encodes tile rows [begin_r, end_r) of every frame
-(`stripe_bounds`).  The only exchange on the data path is the all-reduce of the per-stream symbol
-histograms (RCCL over xGMI on GPUs, gloo in the CPU tests) that feeds the Huffman/Golomb tables.  The
-per-tile records themselves are gathered to rank 0 (they are what the container is made of): the DC
-difference chains and the run-length variant depend on the reference's x-outer / y-inner tile order
-across stripes (CompressedImage.cpp:428-453, 535-537), which no histogram captures.
+The tile encode is embarrassingly parallel: rank r encodes tile rows [begin_r, end_r) of EVERY frame of a step
+(`stripe_bounds`, one launch).  A container, however, is one bit stream per frame in the reference's x-outer / y-inner tile
+order: DC difference chains and run-length coding run across stripe boundaries inside every tile column
+(CompressedImage.cpp:428-453, 535-537), so a frame's records must meet in one place before they are coded.
+With N frames per step (weak scaling) frame f is OWNED by rank f: every rank sends its stripe of frame f to rank f
+(`exchange_stripes`: batched point-to-point, RCCL over xGMI on GPUs, gloo in the CPU tests; exact sizes, u16 counts and
+u32 records as they are), the owner interleaves the N stripes into frame order and runs stream assembly + entropy stage.
+That is the path's only exchange, and every rank does an equal share of the host work.
+
+The symbol-histogram all-reduce the survey sketched is not on this path: a histogram cannot carry what decides the
+bytes (first-occurrence order of the symbols for the Huffman ties, run lengths, DC chains), and the frame's owner gets the
+histogram of its own frame for free while it codes it.  `histogram_of_records` / `allreduce_histogram` remain for callers
+that want global statistics (mpc_histogram_device is their device form).
 """
 import numpy as np
 
@@ -21,18 +28,79 @@ def stripe_bounds(tiles_y, world, rank):
 
 def interleave_stripes(parts, tiles_x, tiles_y, world):
     """parts[r] = array [tiles_x * rows_r, ...] in the C ABI's stripe order (t = tx*rows_r + ty_local) ->
-    whole-frame array [tiles_x * tiles_y, ...] in the reference's order (t = tx*tiles_y + ty)."""
-    tail = parts[0].shape[1:]
-    out = np.empty((tiles_x, tiles_y) + tail, parts[0].dtype)
+    whole-frame array [tiles_x * tiles_y, ...] in the reference's order (t = tx*tiles_y + ty).  numpy arrays or torch tensors."""
+    tail = tuple(parts[0].shape[1:])
+    if isinstance(parts[0], np.ndarray):
+        out = np.empty((tiles_x, tiles_y) + tail, parts[0].dtype)
+    else:
+        import torch
+        out = torch.empty((tiles_x, tiles_y) + tail, dtype=parts[0].dtype, device=parts[0].device)
     for r in range(world):
         b, e = stripe_bounds(tiles_y, world, r)
         out[:, b:e] = parts[r].reshape((tiles_x, e - b) + tail)
     return out.reshape((tiles_x * tiles_y,) + tail)
 
 
+def exchange_stripes(dist, mine, tiles_x, tiles_y, via_cpu=False):
+    """mine[f] = this rank's stripe of frame f (torch tensor [tiles_x * rows_mine, ...]), f = 0 .. world-1.
+    Returns parts[r] = rank r's stripe of the frame THIS rank owns (frame index = rank), exact sizes, dtype kept.
+    via_cpu: stage through host memory (gloo has no device point-to-point)."""
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    tail = tuple(mine[0].shape[1:])
+    dev = mine[0].device
+    send = [m.cpu() if via_cpu else m for m in mine]
+    parts = []
+    for r in range(world):
+        b, e = stripe_bounds(tiles_y, world, r)
+        parts.append(torch.empty((tiles_x * (e - b),) + tail, dtype=mine[0].dtype, device="cpu" if via_cpu else dev))
+    ops = []
+    for r in range(world):
+        if r == rank:
+            parts[r].copy_(send[r])
+            continue
+        ops.append(dist.P2POp(dist.isend, send[r].contiguous(), r))
+        ops.append(dist.P2POp(dist.irecv, parts[r], r))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return [p.to(dev) for p in parts] if via_cpu else parts
+
+
+class StripedEncoder:
+    """One step of the N > 1 path on a GPU: stripe encode of every frame (one launch), stripe exchange, interleave, this
+    rank's frame -> container bytes (device stream assembly + host entropy stage)."""
+
+    def __init__(self, ctx, width, height, frames, world, rank, backend):
+        import torch
+        import torch.distributed as dist
+        if frames != world:
+            raise ValueError("weak scaling: one frame per rank and step")
+        self.ctx, self.W, self.H, self.world, self.rank, self.dist = ctx, width, height, world, rank, dist
+        self.via_cpu = backend != "nccl"
+        self.tiles_x, self.tiles_y = (width + 7) // 8, (height + 7) // 8
+        self.begin, self.end = stripe_bounds(self.tiles_y, world, rank)
+        per_frame = self.tiles_x * (self.end - self.begin)
+        K = ctx.K
+        self.counts = torch.zeros((frames, per_frame, 3), dtype=torch.int16, device="cuda")
+        self.choices = torch.zeros((frames, per_frame, 3, K), dtype=torch.int32, device="cuda")
+        ctx.reserve(frames * per_frame)
+
+    def step(self, d_rgb, stream):
+        W, H = self.W, self.H
+        self.ctx.encode_batch_device(d_rgb.data_ptr(), self.world, W * H * 3, W, H, W * 3, self.begin, self.end,
+                                     self.counts.data_ptr(), self.choices.data_ptr(), stream=stream.cuda_stream)
+        cparts = exchange_stripes(self.dist, list(self.counts), self.tiles_x, self.tiles_y, self.via_cpu)
+        hparts = exchange_stripes(self.dist, list(self.choices), self.tiles_x, self.tiles_y, self.via_cpu)
+        counts = interleave_stripes(cparts, self.tiles_x, self.tiles_y, self.world).contiguous()
+        choices = interleave_stripes(hparts, self.tiles_x, self.tiles_y, self.world).contiguous()
+        return self.ctx.records_to_container_device(counts.data_ptr(), choices.data_ptr(), W, H, stream=stream.cuda_stream)
+
+
 def histogram_of_records(counts, choices, K):
     """numpy form of the device histogram kernel: [(1 + 6K), 8192] uint32; stream 0 = lengths,
-    1 + 2K*ch + 2i = deltaId at step i, +1 = intCoeff at step i.  choices: uint32 [T,3,K]."""
+    1 + 2K*ch + 2i = deltaId at step i, +1 = intCoeff at step i.  choices: uint32 [T,3,K].  Symbols >= 8192 (possible only
+    with custom quantisers far below the data) are not counted, here and on the device."""
     hist = np.zeros((1 + 6 * K, HIST_BINS), np.int64)
     hist[0] = np.bincount(counts.reshape(-1), minlength=HIST_BINS)[:HIST_BINS]
     for ch in range(3):
@@ -44,36 +112,8 @@ def histogram_of_records(counts, choices, K):
     return hist
 
 
-def gather_records(dist, counts, choices, tiles_x, tiles_y, K, device="cpu"):
-    """All ranks call this with their stripe's records (numpy). Rank 0 gets (counts[T,3], choices[T,3,K]) of the
-    whole frame in the reference's tile order; the others get (None, None).  Stripes differ in size, so the
-    tensors are padded to the largest stripe for the collective."""
-    import torch
-    world, rank = dist.get_world_size(), dist.get_rank()
-    max_rows = max(stripe_bounds(tiles_y, world, r)[1] - stripe_bounds(tiles_y, world, r)[0] for r in range(world))
-    pad = tiles_x * max_rows
-    n = counts.shape[0]
-    c = torch.zeros((pad, 3), dtype=torch.int32, device=device)
-    h = torch.zeros((pad, 3, K), dtype=torch.int64, device=device)
-    c[:n] = torch.from_numpy(counts.astype(np.int32)).to(device)
-    h[:n] = torch.from_numpy(choices.astype(np.int64)).to(device)
-    cs = [torch.zeros_like(c) for _ in range(world)] if rank == 0 else None
-    hs = [torch.zeros_like(h) for _ in range(world)] if rank == 0 else None
-    dist.gather(c, cs, dst=0)
-    dist.gather(h, hs, dst=0)
-    if rank != 0:
-        return None, None
-    cparts, hparts = [], []
-    for r in range(world):
-        b, e = stripe_bounds(tiles_y, world, r)
-        m = tiles_x * (e - b)
-        cparts.append(cs[r][:m].cpu().numpy().astype(np.uint16))
-        hparts.append(hs[r][:m].cpu().numpy().astype(np.uint32))
-    return (interleave_stripes(cparts, tiles_x, tiles_y, world), interleave_stripes(hparts, tiles_x, tiles_y, world))
-
-
 def allreduce_histogram(dist, hist, device="cpu"):
-    """Sum of the ranks' histograms on every rank (the path's only data-path collective)."""
+    """Sum of the ranks' histograms on every rank."""
     import torch
     t = torch.from_numpy(np.ascontiguousarray(hist, np.int64)).to(device)
     dist.all_reduce(t)

@@ -141,11 +141,14 @@ mpc_status mpc_calc_mp_batch(mpc_context* ctx, int channel, const double* quant_
  * joined to the caller's stream with events); at most 262144 tiles are in flight. */
 mpc_status mpc_reserve(mpc_context* ctx, long long max_tiles);
 
-/* Live timing of the dominant kernel (the filtered base sweep, mp_filter_wave_kernel): while enabled every launch of it is
+/* Live timing of the dominant kernel (mp_pursuit_kernel, one launch per channel): while enabled every launch of it is
  * bracketed by HIP events on the stream it is launched on.  mpc_kernel_timing_read synchronises and returns, for
  * the launches since the last read/enable: the summed duration, their number, and (busy_ms, may be NULL) the
  * length of the union of their intervals -- launches of the two internal streams overlap.  Measurement only. */
 void mpc_kernel_timing_enable(mpc_context* ctx, int on);
+/* What the pursuit kernel itself counted since mpc_kernel_timing_enable(ctx, 1) or the last read (every wave adds its tallies
+ * once, at exit): v_mfma_f32_16x16x32_bf16 instructions executed (16384 flop each) and tile-channel-steps.  Synchronises. */
+mpc_status mpc_kernel_counters_read(mpc_context* ctx, unsigned long long* mfma_instructions, unsigned long long* tile_channel_steps);
 mpc_status mpc_kernel_timing_read(mpc_context* ctx, double* total_ms, long long* launches, double* busy_ms);
 
 /* ---- host entropy stage and container (stays on the host; bytes identical to the reference) ----------
@@ -205,6 +208,12 @@ mpc_status mpc_encode_image_device(mpc_context* ctx, const uint8_t* d_rgb, int w
                                    uint8_t** bytes, size_t* nbytes);
 mpc_status mpc_encode_images_device(mpc_context* ctx, const uint8_t* const* d_rgb_frames, int n_frames, int width, int height,
                                     const double* quant, uint8_t** bytes, size_t* nbytes);
+
+/* The second half of encodeImage (CompressedImage.cpp:555-575) for records that are already in device memory in whole-frame
+ * order, tile t = tx*tiles_y + ty (a frame's owner in the multi-GPU path after the stripe exchange): stream assembly on the
+ * device (on `stream`), live symbols to the host, entropy stage.  Synchronises `stream`. */
+mpc_status mpc_records_to_container_device(mpc_context* ctx, const uint16_t* d_counts, const mpc_basis_choice* d_choices, int width,
+                                           int height, const double* quant, void* stream, uint8_t** bytes, size_t* nbytes);
 
 /* matching::FromCoeffsDynamic (MatchingPursuit.h:25) + img::RGBFromYUV for every tile of a frame on the device:
  * records in the reference's order (tile t = tx*tiles_y + ty, as mpc_encode_tiles returns them for the whole
