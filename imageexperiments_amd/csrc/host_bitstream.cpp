@@ -170,6 +170,8 @@ uint32_t golomb_read(uint32_t m, BitReader& in) {
 namespace {
 
 // Elias-Fano coding of a non-decreasing u16 sequence (BitBuffer.cpp:292-354)
+}  // namespace
+
 uint32_t elias_fano_length(size_t n, uint16_t max_symbol) {
     if (n == 0) return 0;
     const uint32_t m = bit_width(max_symbol), nb = bit_width(static_cast<uint32_t>(n));
@@ -207,6 +209,7 @@ bool elias_fano_read(uint16_t* dst, size_t n, uint16_t max_symbol, BitReader& in
     return true;
 }
 
+namespace {
 // ------------------------------------------------------------------------------------------------
 // Iteration order of MSVC's std::unordered_map<uint32_t, T> after a given insertion sequence.
 //

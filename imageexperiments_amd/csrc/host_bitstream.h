@@ -49,6 +49,11 @@ uint32_t golomb_length(uint32_t value, uint32_t m);
 void golomb_write(uint32_t value, uint32_t m, BitWriter& out);
 uint32_t golomb_read(uint32_t m, BitReader& in);
 
+// Elias-Fano code of a sorted sequence (BitBuffer.cpp:292-354): the Huffman symbol table uses it where it is shorter than raw
+uint32_t elias_fano_length(size_t n, uint16_t max_symbol);
+void elias_fano_write(const uint16_t* seq, size_t n, uint16_t max_symbol, BitWriter& out);
+bool elias_fano_read(uint16_t* dst, size_t n, uint16_t max_symbol, BitReader& in);
+
 void huffman_encode(const uint16_t* data, size_t n, BitWriter& out);
 bool huffman_decode(BitReader& in, std::vector<uint16_t>& out);          // false = "Invalid bitstream"
 

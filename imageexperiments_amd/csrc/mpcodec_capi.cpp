@@ -1015,6 +1015,78 @@ mpc_status mpc_rle_decode(const uint16_t* data, size_t n, uint16_t** out, size_t
     });
 }
 
+// ---- bit-level primitives of CompressionLib/inc/BitBuffer.h, as the entropy stage uses them ----
+uint32_t mpc_zigzag_encode(int32_t x) { return mpc::zigzag_encode(x); }
+int32_t mpc_zigzag_decode(uint32_t x) { return mpc::zigzag_decode(x); }
+uint32_t mpc_golomb_length(uint32_t value, uint32_t m) { return m ? mpc::golomb_length(value, m) : 0; }
+uint32_t mpc_elias_fano_length(size_t n, uint16_t max_symbol) { return mpc::elias_fano_length(n, max_symbol); }
+
+mpc_status mpc_bits_pack(const uint64_t* values, const int* widths, size_t n, uint8_t** bytes, size_t* nbytes, size_t* nbits) {
+    return guarded([&]() -> mpc_status {
+    if ((!values || !widths) && n) return fail(MPC_ERR_ARGUMENT, "null argument");
+    if (!bytes || !nbytes || !nbits) return fail(MPC_ERR_ARGUMENT, "null argument");
+    mpc::BitWriter w;
+    for (size_t i = 0; i < n; ++i) {
+        if (widths[i] < 0 || widths[i] > 64) return fail(MPC_ERR_ARGUMENT, "Invalid bit width");      // BitBuffer.cpp:80 throws here
+        w.put(values[i], widths[i]);
+    }
+    *nbits = w.bit_size();
+    *bytes = give_bytes(w.bytes(), nbytes);
+    return *bytes ? MPC_OK : fail(MPC_ERR_ALLOC, "out of memory");
+    });
+}
+
+mpc_status mpc_bits_unpack(const uint8_t* bytes, size_t nbytes, const int* widths, size_t n, uint64_t* values, size_t* remaining_bits) {
+    if ((!bytes && nbytes) || ((!widths || !values) && n)) return fail(MPC_ERR_ARGUMENT, "null argument");
+    mpc::BitReader r(bytes, nbytes);
+    for (size_t i = 0; i < n; ++i) {
+        if (widths[i] < 0 || widths[i] > 64) return fail(MPC_ERR_ARGUMENT, "Invalid bit width");
+        values[i] = r.get(widths[i]);
+    }
+    if (remaining_bits) *remaining_bits = r.remaining();
+    return MPC_OK;
+}
+
+mpc_status mpc_golomb_encode(const uint32_t* values, size_t n, uint32_t m, uint8_t** bytes, size_t* nbytes, size_t* nbits) {
+    return guarded([&]() -> mpc_status {
+    if ((!values && n) || !bytes || !nbytes || !nbits || m == 0) return fail(MPC_ERR_ARGUMENT, "bad argument");
+    mpc::BitWriter w;
+    for (size_t i = 0; i < n; ++i) mpc::golomb_write(values[i], m, w);
+    *nbits = w.bit_size();
+    *bytes = give_bytes(w.bytes(), nbytes);
+    return *bytes ? MPC_OK : fail(MPC_ERR_ALLOC, "out of memory");
+    });
+}
+
+mpc_status mpc_golomb_decode(const uint8_t* bytes, size_t nbytes, size_t n, uint32_t m, uint32_t* values, size_t* remaining_bits) {
+    if ((!bytes && nbytes) || (!values && n) || m == 0) return fail(MPC_ERR_ARGUMENT, "bad argument");
+    mpc::BitReader r(bytes, nbytes);
+    for (size_t i = 0; i < n; ++i) values[i] = mpc::golomb_read(m, r);
+    if (remaining_bits) *remaining_bits = r.remaining();
+    return MPC_OK;
+}
+
+mpc_status mpc_elias_fano_encode(const uint16_t* sorted, size_t n, uint16_t max_symbol, uint8_t** bytes, size_t* nbytes, size_t* nbits) {
+    return guarded([&]() -> mpc_status {
+    if ((!sorted && n) || !bytes || !nbytes || !nbits) return fail(MPC_ERR_ARGUMENT, "null argument");
+    for (size_t i = 0; i < n; ++i)
+        if (sorted[i] > max_symbol || (i && sorted[i] < sorted[i - 1])) return fail(MPC_ERR_ARGUMENT, "sequence not sorted or beyond max_symbol");
+    mpc::BitWriter w;
+    mpc::elias_fano_write(sorted, n, max_symbol, w);
+    *nbits = w.bit_size();
+    *bytes = give_bytes(w.bytes(), nbytes);
+    return *bytes ? MPC_OK : fail(MPC_ERR_ALLOC, "out of memory");
+    });
+}
+
+mpc_status mpc_elias_fano_decode(const uint8_t* bytes, size_t nbytes, size_t n, uint16_t max_symbol, uint16_t* sorted, size_t* remaining_bits) {
+    if ((!bytes && nbytes) || (!sorted && n)) return fail(MPC_ERR_ARGUMENT, "null argument");
+    mpc::BitReader r(bytes, nbytes);
+    if (!mpc::elias_fano_read(sorted, n, max_symbol, r)) return fail(MPC_ERR_BITSTREAM, "Invalid bitstream");
+    if (remaining_bits) *remaining_bits = r.remaining();
+    return MPC_OK;
+}
+
 // compressed::encodeImage for a sequence of equally sized frames: device tile encode, device stream assembly (only the live
 // symbols cross PCIe, stream by stream), host entropy stage -- pipelined over kSeqSlots slots.  Frames come from host memory
 // (uploaded through the slot's pinned image on an upload stream) or are already resident on the device.

@@ -190,6 +190,23 @@ mpc_status mpc_huffman_decode(const uint8_t* bytes, size_t nbytes, uint16_t** da
 mpc_status mpc_rle_encode(const uint16_t* data, size_t n, uint16_t** out, size_t* n_out);
 mpc_status mpc_rle_decode(const uint16_t* data, size_t n, uint16_t** out, size_t* n_out);
 
+/* Bit-level primitives of bitbuffer:: (CompressionLib/inc/BitBuffer.h) as the entropy stage uses them; the property tests of
+ * Testing/BitBufferTests.cpp:37-247 run against these (tests/test_bit_primitives.py).
+ *   mpc_bits_pack / _unpack      BitBuffer::WriteBits / ReadBits + Save / Load (MSB first, widths 0..64; reads past the end give 0)
+ *   mpc_zigzag_*                 zigzagEncode / zigzagDecode                    BitBuffer.h:112-118
+ *   mpc_golomb_*                 golombCodeLength / writeGolombCode / readGolombCode   BitBuffer.cpp:228-269
+ *   mpc_elias_fano_*             eliasFanoSequenceCodeLength / write / read           BitBuffer.cpp:292-354 */
+mpc_status mpc_bits_pack(const uint64_t* values, const int* widths, size_t n, uint8_t** bytes, size_t* nbytes, size_t* nbits);
+mpc_status mpc_bits_unpack(const uint8_t* bytes, size_t nbytes, const int* widths, size_t n, uint64_t* values, size_t* remaining_bits);
+uint32_t mpc_zigzag_encode(int32_t x);
+int32_t mpc_zigzag_decode(uint32_t x);
+uint32_t mpc_golomb_length(uint32_t value, uint32_t m);
+mpc_status mpc_golomb_encode(const uint32_t* values, size_t n, uint32_t m, uint8_t** bytes, size_t* nbytes, size_t* nbits);
+mpc_status mpc_golomb_decode(const uint8_t* bytes, size_t nbytes, size_t n, uint32_t m, uint32_t* values, size_t* remaining_bits);
+uint32_t mpc_elias_fano_length(size_t n, uint16_t max_symbol);
+mpc_status mpc_elias_fano_encode(const uint16_t* sorted, size_t n, uint16_t max_symbol, uint8_t** bytes, size_t* nbytes, size_t* nbits);
+mpc_status mpc_elias_fano_decode(const uint8_t* bytes, size_t nbytes, size_t n, uint16_t max_symbol, uint16_t* sorted, size_t* remaining_bits);
+
 /* compressed::encodeImage (CompressedImage.h:59): rgb host buffer, 3*width bytes per row; quant NULL = context
  * tables.  Tile encode on the device, entropy stage on the host. */
 mpc_status mpc_encode_image(mpc_context* ctx, const uint8_t* rgb, int width, int height, const double* quant,

@@ -53,7 +53,7 @@ _ref = None
 def lib():
     global _lib
     if _lib is None:
-        path = os.path.join(HERE, "_build", "liboracle.so")
+        path = os.environ.get("ORACLE_LIB") or os.path.join(HERE, "_build", "liboracle.so")     # ORACLE_LIB: `make asan-oracle`
         if not os.path.exists(path):
             build(ref=False)
         L = C.CDLL(path)
