@@ -38,22 +38,27 @@ void BitWriter::put_codes(const uint16_t* data, size_t n, const uint32_t* code_o
     size_t word = nbits_ >> 6;
     int used = static_cast<int>(nbits_ & 63);
     uint64_t acc = used ? words_[word] >> (64 - used) : 0;     // the bits already in the current word, right-aligned
-    for (size_t i = 0; i < n; ++i) {
-        const uint16_t s = data[i];
-        const int len = length_of[s];
-        const uint64_t code = code_of[s];
+    uint64_t* const dst = words_.data();
+    auto emit = [&](uint64_t code, int len) {                  // len 1..64
         if (used + len <= 64) {
             acc = (len == 64) ? code : ((acc << len) | code);
             used += len;
-            if (used == 64) { words_[word++] = acc; acc = 0; used = 0; }
+            if (used == 64) { dst[word++] = acc; acc = 0; used = 0; }
         } else {
             const int spill = used + len - 64;                 // low `spill` bits go to the next word
-            words_[word++] = (acc << (len - spill)) | (code >> spill);
+            dst[word++] = (acc << (len - spill)) | (code >> spill);
             acc = code & ((1ULL << spill) - 1ULL);
             used = spill;
         }
+    };
+    size_t i = 0;
+    for (; i + 1 < n; i += 2) {                                 // two codes (<= 32 bits each) joined into one emission
+        const uint16_t a = data[i], b = data[i + 1];
+        const int lb = length_of[b];
+        emit((static_cast<uint64_t>(code_of[a]) << lb) | code_of[b], length_of[a] + lb);
     }
-    words_[word] = used ? acc << (64 - used) : 0;
+    if (i < n) emit(code_of[data[i]], length_of[data[i]]);
+    dst[word] = used ? acc << (64 - used) : 0;
     nbits_ += total_bits;
 }
 
@@ -331,11 +336,70 @@ struct SymbolStats {
 
 SymbolStats gather_stats(const uint16_t* data, size_t n) {
     SymbolStats st;
-    for (size_t i = 0; i < n; ++i) st.largest = std::max(st.largest, data[i]);
-    st.hist.assign(static_cast<size_t>(st.largest) + 1, 0);
-    for (size_t i = 0; i < n; ++i)
-        if (st.hist[data[i]]++ == 0) st.distinct.push_back(data[i]);
+    uint16_t largest = 0;
+    for (size_t i = 0; i < n; ++i) largest = std::max(largest, data[i]);       // vectorises
+    st.largest = largest;
+    const size_t bins = static_cast<size_t>(largest) + 1;
+    st.hist.assign(bins, 0);
+    if (n >= 4096 && bins <= 4096) {
+        // long stream, few symbols: consecutive increments of one counter wait for each other (store forwarding); four
+        // interleaved tables break the chain
+        thread_local std::vector<uint32_t> lanes;
+        lanes.assign(4 * bins, 0);
+        uint32_t* h0 = lanes.data();
+        uint32_t* h1 = h0 + bins;
+        uint32_t* h2 = h1 + bins;
+        uint32_t* h3 = h2 + bins;
+        size_t i = 0;
+        for (; i + 3 < n; i += 4) { ++h0[data[i]]; ++h1[data[i + 1]]; ++h2[data[i + 2]]; ++h3[data[i + 3]]; }
+        for (; i < n; ++i) ++h0[data[i]];
+        size_t present = 0;
+        for (size_t b = 0; b < bins; ++b) {
+            st.hist[b] = h0[b] + h1[b] + h2[b] + h3[b];
+            present += st.hist[b] != 0;
+        }
+        // order of first appearance: scan until every symbol that occurs has been seen
+        std::vector<uint8_t> seen(bins, 0);
+        st.distinct.reserve(present);
+        for (size_t k = 0; k < n && st.distinct.size() < present; ++k)
+            if (!seen[data[k]]) { seen[data[k]] = 1; st.distinct.push_back(data[k]); }
+    } else {
+        for (size_t i = 0; i < n; ++i)
+            if (st.hist[data[i]]++ == 0) st.distinct.push_back(data[i]);
+    }
     return st;
+}
+
+// Number of symbols runLengthEncode would emit, without emitting them: a maximal run of L equal symbols becomes 1 symbol
+// (L = 1) or 3 (symbol, symbol, L - 2); runs beyond 0x8001 symbols are cut by the reference's counter limit (Huffman.cpp:
+// 262-267) -- if any run can be that long the literal state machine decides.
+size_t rle_encoded_size(const uint16_t* data, size_t n) {
+    if (n == 0) return 0;
+    size_t equal = 0, long_starts = 0;                          // data[i] == data[i-1]; ... and data[i-1] != data[i-2]
+    for (size_t i = 1; i < n; ++i) {
+        const bool e = data[i] == data[i - 1];
+        const bool before = i >= 2 && data[i - 1] == data[i - 2];
+        equal += e;
+        long_starts += e && !before;
+    }
+    if (equal < 0x8000) return (n - equal) + 2 * long_starts;
+    size_t packed = 0;
+    uint16_t prev = 0, run = 0;
+    bool fresh = true;
+    for (size_t i = 0; i < n; ++i) {
+        const uint16_t v = data[i];
+        if (v == prev && !fresh) {
+            if (++run == 1) ++packed;
+            else if (run >= 0x8000) { ++packed; run = 0; fresh = true; }
+        } else {
+            fresh = false;
+            if (run > 0) { ++packed; run = 0; }
+            prev = v;
+            ++packed;
+        }
+    }
+    if (run > 0) ++packed;
+    return packed;
 }
 
 void huffman_encode_with(const SymbolStats& st, const uint16_t* data, size_t n, BitWriter& out);
@@ -774,8 +838,9 @@ std::vector<uint8_t> write_compressed(const Streams& s) {
         const bool dc = (i == 1 || i == 2 * K + 1 || i == 4 * K + 1);
         const std::vector<uint16_t> diffed = dc ? dc_difference(s.codes[i]) : std::vector<uint16_t>();
         const std::vector<uint16_t>& stream = dc ? diffed : s.codes[i];
-        const std::vector<uint16_t> packed = rle_encode(stream.data(), stream.size());
-        if (packed.size() + 4 < stream.size()) {                 // :450
+        const bool shorter = rle_encoded_size(stream.data(), stream.size()) + 4 < stream.size();
+        const std::vector<uint16_t> packed = shorter ? rle_encode(stream.data(), stream.size()) : std::vector<uint16_t>();
+        if (shorter) {                                           // :450
             w.put(1, 1);
             w.put(static_cast<uint32_t>(packed.size()), 32);
             write_huffman_or_golomb(packed.data(), packed.size(), w);
@@ -815,8 +880,9 @@ void code_records(int width, int height, int K, int block_size, const double* qu
             scratch = dc_difference(stream);
             src = &scratch;
         }
-        const std::vector<uint16_t> packed = rle_encode(src->data(), src->size());
-        if (packed.size() + 4 < src->size()) {                  // :450
+        const bool shorter = rle_encoded_size(src->data(), src->size()) + 4 < src->size();
+        const std::vector<uint16_t> packed = shorter ? rle_encode(src->data(), src->size()) : std::vector<uint16_t>();
+        if (shorter) {                                          // :450
             w.put(1, 1);
             w.put(static_cast<uint32_t>(packed.size()), 32);
             write_huffman_or_golomb(packed.data(), packed.size(), w);
@@ -946,8 +1012,9 @@ uint8_t* encode_symbol_streams_malloc(int width, int height, int K, int block_si
         const uint16_t* data = symbols + off[s];
         const size_t n = static_cast<size_t>(off[s + 1] - off[s]);
         BitWriter& w = parts[static_cast<size_t>(s + 1)];
-        const std::vector<uint16_t> packed = rle_encode(data, n);
-        if (packed.size() + 4 < n) {                              // CompressedImage.cpp:450
+        const bool shorter = rle_encoded_size(data, n) + 4 < n;
+        const std::vector<uint16_t> packed = shorter ? rle_encode(data, n) : std::vector<uint16_t>();
+        if (shorter) {                                            // CompressedImage.cpp:450
             w.put(1, 1);
             w.put(static_cast<uint32_t>(packed.size()), 32);
             write_huffman_or_golomb(packed.data(), packed.size(), w);

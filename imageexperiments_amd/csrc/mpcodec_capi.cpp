@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -934,6 +935,19 @@ mpc_status mpc_assemble_planar_streams(int width, int height, int K, int block_s
     });
 }
 
+mpc_status mpc_assemble_symbol_streams(int width, int height, int K, int block_size, const double* quant, const uint16_t* counts,
+                                       const uint16_t* symbols, const unsigned long long* stream_off, uint8_t** bytes, size_t* nbytes) {
+    return guarded([&]() -> mpc_status {
+    if (!quant || !counts || (!symbols && stream_off && stream_off[6 * K]) || !stream_off || !bytes || !nbytes || K < 1 || K > MPC_MAX_K ||
+        block_size < 1 || width < 1 || height < 1)
+        return fail(MPC_ERR_ARGUMENT, "bad argument");
+    for (int s = 0; s < 6 * K; ++s)
+        if (stream_off[s + 1] < stream_off[s]) return fail(MPC_ERR_ARGUMENT, "stream offsets must not decrease");
+    *bytes = mpc::encode_symbol_streams_malloc(width, height, K, block_size, quant, counts, symbols, stream_off, nbytes);
+    return *bytes ? MPC_OK : fail(MPC_ERR_ALLOC, "out of memory");
+    });
+}
+
 mpc_status mpc_read_compressed(const uint8_t* bytes, size_t nbytes, mpc_streams** out) {
     return guarded([&]() -> mpc_status {
     if (!bytes || !out) return fail(MPC_ERR_ARGUMENT, "null argument");
@@ -1138,8 +1152,9 @@ static mpc_status encode_sequence(mpc_context* c, const uint8_t* const* frames, 
         HIP_TRY(hipStreamCreateWithFlags(&c->seq_up, hipStreamNonBlocking));
         HIP_TRY(hipStreamCreateWithFlags(&c->seq_compute, hipStreamNonBlocking));
         for (auto& s : c->seq_down) HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        // blocking events: a thread waiting for the device sleeps instead of spinning (the entropy stage wants the cores)
         for (auto& slot : c->seq_events)
-            for (hipEvent_t& e : slot) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            for (hipEvent_t& e : slot) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventBlockingSync));
     }
     HIP_TRY(ensure_workspace(c, static_cast<long long>(n_tc)) == MPC_OK ? hipSuccess : hipErrorOutOfMemory);
     const double* q = quant ? quant : c->quant.data();
@@ -1224,17 +1239,29 @@ static mpc_status encode_sequence(mpc_context* c, const uint8_t* const* frames, 
         const size_t n_off = 6 * static_cast<size_t>(K) + 1;
         slot.frame = f;
         // the slot's worker: wait for the device, fetch the stream boundaries, then exactly the live symbols, then code them
+        hipEvent_t ev_down = c->seq_events[sl][2];
+        static const bool trace = env_int("MPC_TRACE", 0) != 0;
+        static const auto t_origin = std::chrono::steady_clock::now();
+        auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_origin).count(); };
+        const double t_enq = now_ms();
         slot.result = std::async(std::launch::async, [=]() -> std::pair<uint8_t*, size_t> {
-            if (hipSetDevice(device) != hipSuccess || hipStreamWaitEvent(down, ev_comp, 0) != hipSuccess) return {nullptr, 0};
+            struct Trace {
+                bool on; int f; double t0, t1 = 0, t2 = 0, t3 = 0;
+                ~Trace() { if (on) std::fprintf(stderr, "[trace] frame %d enqueued %.2f | device done %.2f | symbols on host %.2f | coded %.2f\n", f, t0, t1, t2, t3); }
+            } tr{trace, f, t_enq};
+            if (hipSetDevice(device) != hipSuccess || hipEventSynchronize(ev_comp) != hipSuccess) return {nullptr, 0};
+            tr.t1 = now_ms();
             if (hipMemcpyAsync(off, d_off, sizeof(unsigned long long) * n_off, hipMemcpyDeviceToHost, down) != hipSuccess) return {nullptr, 0};
             if (hipMemcpyAsync(counts, d_counts, sizeof(uint16_t) * n_tc, hipMemcpyDeviceToHost, down) != hipSuccess) return {nullptr, 0};
-            if (hipStreamSynchronize(down) != hipSuccess) return {nullptr, 0};
+            if (hipEventRecord(ev_down, down) != hipSuccess || hipEventSynchronize(ev_down) != hipSuccess) return {nullptr, 0};
             const unsigned long long total = off[n_off - 1];
             if (total > 2ULL * n_tc * static_cast<unsigned long long>(K)) return {nullptr, 0};
             if (total && hipMemcpyAsync(symbols, d_symbols, sizeof(uint16_t) * total, hipMemcpyDeviceToHost, down) != hipSuccess) return {nullptr, 0};
-            if (hipStreamSynchronize(down) != hipSuccess) return {nullptr, 0};
+            if (hipEventRecord(ev_down, down) != hipSuccess || hipEventSynchronize(ev_down) != hipSuccess) return {nullptr, 0};
+            tr.t2 = now_ms();
             size_t n = 0;
             uint8_t* blob = mpc::encode_symbol_streams_malloc(width, height, K, bs, q, counts, symbols, off, &n);
+            tr.t3 = now_ms();
             return {blob, n};
         });
     }

@@ -175,6 +175,12 @@ mpc_status mpc_assemble_streams(int width, int height, int K, int block_size, co
 mpc_status mpc_assemble_planar_streams(int width, int height, int K, int block_size, const double* quant,
                                        const uint16_t* counts, const mpc_basis_choice* planar, uint8_t** bytes, size_t* nbytes);
 
+/* Same container from streams that are already assembled (what the device's stream assembly hands the host): symbols =
+ * codes[0] ++ codes[1] ++ ... ++ codes[6K-1], live symbols only, tiles in the reference's order, the three step-0 coefficient
+ * streams ALREADY difference coded (CompressedImage.cpp:428-446); stream_off[6K + 1] = their boundaries in `symbols`. */
+mpc_status mpc_assemble_symbol_streams(int width, int height, int K, int block_size, const double* quant, const uint16_t* counts,
+                                       const uint16_t* symbols, const unsigned long long* stream_off, uint8_t** bytes, size_t* nbytes);
+
 /* readCompressed (CompressedImage.cpp:635): parse a container; streams come back with the DC differencing
  * undone.  index -1 = lengths, 0..6K-1 = codes[index]. */
 mpc_status mpc_read_compressed(const uint8_t* bytes, size_t nbytes, mpc_streams** out);

@@ -35,21 +35,27 @@ def main():
                       "WRITE_SIZE_KB_per_frame": round(wt.get(k, 0.0) / frames, 1)}
     fetch_b = sum(ft.values()) / frames * 1024
     write_b = sum(wt.values()) / frames * 1024
+    per_launch = {}
+    for k in kernels:                                        # what bench.py reads: roofline.traffic of the dominant kernel, per launch
+        launches = max(fn.get(k, 0), wn.get(k, 0), 1)
+        fb, wb = ft.get(k, 0.0) / launches * 1024, wt.get(k, 0.0) / launches * 1024
+        per_launch[k] = {"launches_profiled": launches, "raw_fetch_bytes_per_launch": int(fb), "write_bytes_per_launch": int(wb),
+                         "hbm_bytes_per_launch": int(2 * fb + wb)}
     doc = {
         "workload": workload,
         "collected": "two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of bench.py --no-cpu, kernel-trace/stats not combined",
-        "units": "counter values are KB (x1024 = bytes); per frame = per bench step = one K-step pursuit of the workload",
+        "units": "counter values are KB (x1024 = bytes); per frame = per step of the profiled command",
         "per_kernel": kernels,
         "raw_fetch_bytes_per_launch": int(fetch_b),
         "write_bytes_per_launch": int(write_b),
         "gfx950_correction": "MI355X_MICROARCH.md: FETCH_SIZE reads exactly 1/2 of the bytes of wide coalesced 16 B/lane streams; other "
                              "widths uncalibrated.  Most reads here are 16 B/lane, so 2 x FETCH + WRITE is reported (an upper bound).",
-        "hbm_bytes_per_launch": int(2 * fetch_b + write_b),
-        "note": "'launch' = the whole K-step pursuit of one frame (one bench step); bench.py reports this figure as roofline.traffic",
+        "hbm_bytes_per_step_all_kernels": int(2 * fetch_b + write_b),
     }
+    doc.update(per_launch)
     with open(out, "w") as f:
         json.dump(doc, f, indent=1)
-    print(json.dumps({k: doc[k] for k in ("raw_fetch_bytes_per_launch", "write_bytes_per_launch", "hbm_bytes_per_launch")}))
+    print(json.dumps(per_launch))
 
 
 if __name__ == "__main__":
