@@ -89,6 +89,11 @@ def _bind_bitstream(L):
                                        C.POINTER(_u8p), C.POINTER(C.c_size_t)]
     L.mpc_assemble_planar_streams.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _dp, _u16p, vp,
                                        C.POINTER(_u8p), C.POINTER(C.c_size_t)]
+    _ullp = C.POINTER(C.c_ulonglong)
+    for f in ("mpc_assemble_symbol_streams", "mpc_assemble_symbol_streams_by_plan"):
+        getattr(L, f).argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _dp, _u16p, _u16p, _ullp, C.POINTER(_u8p), C.POINTER(C.c_size_t)]
+    L.mpc_code_symbol_streams_device.argtypes = [vp, C.c_int, C.c_int, _dp, _u16p, _u16p, _ullp, C.POINTER(_u8p), C.POINTER(C.c_size_t),
+                                                 C.POINTER(C.c_int)]
     L.mpc_read_compressed.argtypes = [_u8p, C.c_size_t, C.POINTER(vp)]
     L.mpc_streams_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.mpc_streams_quant.argtypes = [vp, _u16p]
@@ -205,6 +210,30 @@ def assemble_planar_streams(width, height, K, block_size, quant, counts, planar)
     out, n = _u8p(), C.c_size_t(0)
     _check(L.mpc_assemble_planar_streams(width, height, K, block_size, q.ctypes.data_as(_dp), cp, pl.ctypes.data_as(C.c_void_p),
                                          C.byref(out), C.byref(n)))
+    return _take_bytes(L, out, n)
+
+
+def _symbol_streams(K, streams):
+    streams = [np.ascontiguousarray(x, np.uint16).ravel() for x in streams]
+    assert len(streams) == 6 * K
+    off = np.zeros(6 * K + 1, np.uint64)
+    off[1:] = np.cumsum([len(x) for x in streams])
+    symbols = np.concatenate(streams) if int(off[-1]) else np.zeros(1, np.uint16)
+    return np.ascontiguousarray(symbols, np.uint16), off
+
+
+def assemble_symbol_streams(width, height, K, block_size, quant, counts, streams, by_plan=False):
+    """Entropy stage + container on the host from streams that are already assembled: streams[6K] = codes[0..6K) (live symbols,
+    the step-0 coefficient streams already difference coded), counts[3*tiles] = the lengths stream.
+    by_plan: take the route of the device-side entropy stage (statistics -> tables and offsets -> codes) on the host."""
+    L = load_library()
+    q = np.ascontiguousarray(quant, np.float64).reshape(3 * K)
+    cn, cp = _u16(counts)
+    symbols, off = _symbol_streams(K, streams)
+    out, n = _u8p(), C.c_size_t(0)
+    fn = L.mpc_assemble_symbol_streams_by_plan if by_plan else L.mpc_assemble_symbol_streams
+    _check(fn(width, height, K, block_size, q.ctypes.data_as(_dp), cp, symbols.ctypes.data_as(_u16p),
+              off.ctypes.data_as(C.POINTER(C.c_ulonglong)), C.byref(out), C.byref(n)))
     return _take_bytes(L, out, n)
 
 
@@ -483,6 +512,20 @@ class CompressionContext:
         out, n = _u8p(), C.c_size_t(0)
         _check(self.L.mpc_records_to_container_device(self.h, d_counts, d_choices, width, height, qp, stream or None, C.byref(out), C.byref(n)))
         return _take_bytes(self.L, out, n)
+
+    def code_symbol_streams_device(self, width, height, counts, streams, quant=None):
+        """mpc_code_symbol_streams_device: assembled streams (host) -> container bytes with the per-symbol work of the entropy
+        stage on the device.  Returns (bytes, route): route 0 = device, 1 = the host route was taken."""
+        qp = None
+        if quant is not None:
+            quant = np.ascontiguousarray(quant, np.float64).reshape(3, self.K)
+            qp = quant.ctypes.data_as(_dp)
+        cn, cp = _u16(counts)
+        symbols, off = _symbol_streams(self.K, streams)
+        out, n, route = _u8p(), C.c_size_t(0), C.c_int(-1)
+        _check(self.L.mpc_code_symbol_streams_device(self.h, width, height, qp, cp, symbols.ctypes.data_as(_u16p),
+                                                     off.ctypes.data_as(C.POINTER(C.c_ulonglong)), C.byref(out), C.byref(n), C.byref(route)))
+        return _take_bytes(self.L, out, n), route.value
 
     def calc_mp(self, channel, vectors, quant_k=None):
         """matching::CalcMPDynamic (MatchingPursuit.h:22) on the device for vectors[n,64].

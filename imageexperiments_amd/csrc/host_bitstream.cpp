@@ -409,7 +409,18 @@ void huffman_encode_with(const SymbolStats& st, const uint16_t* data, size_t n, 
 void huffman_encode(const uint16_t* data, size_t n, BitWriter& out) { huffman_encode_with(gather_stats(data, n), data, n, out); }
 
 namespace {
-void huffman_encode_with(const SymbolStats& st, const uint16_t* data, size_t n, BitWriter& out) {
+// Everything of huffmanEncode that does not touch the symbols one by one: tree, canonical codes, the table header
+// written to `out`; codes and lengths by symbol (dense up to st.largest), the pseudo-EOF code, and the payload's bits.
+struct HuffmanTable {
+    std::vector<uint32_t> code_of;
+    std::vector<uint8_t> length_of;
+    uint32_t eof_code = 0;
+    uint8_t eof_length = 0;
+    uint8_t max_length = 0;
+    size_t payload_bits = 0;
+};
+
+void huffman_table(const SymbolStats& st, size_t n, BitWriter& out, HuffmanTable& t) {
     const size_t table_size = static_cast<size_t>(st.largest) + 1;
     std::vector<uint32_t> symbols(st.distinct.begin(), st.distinct.end());
     std::vector<size_t> freq;
@@ -458,12 +469,11 @@ void huffman_encode_with(const SymbolStats& st, const uint16_t* data, size_t n, 
         return a.length == b.length ? a.symbol < b.symbol : a.length < b.length;
     });
     const uint8_t max_length = std::max<uint8_t>(heap.front().depth, 1);
+    t.max_length = max_length;
     out.put(max_length, 8);
     std::vector<uint16_t> group_sizes;
-    std::vector<uint32_t> code_of(table_size, 0);
-    std::vector<uint8_t> length_of(table_size, 0);
-    uint32_t eof_code = 0;
-    uint8_t eof_length = 0;
+    t.code_of.assign(table_size, 0);
+    t.length_of.assign(table_size, 0);
     uint8_t prev_length = 0;
     uint32_t code = 0, count = 0;
     for (Entry& e : entries) {
@@ -482,8 +492,8 @@ void huffman_encode_with(const SymbolStats& st, const uint16_t* data, size_t n, 
         e.code = code++;
         ++count;
         prev_length = e.length;
-        if (e.symbol == kPseudoEof) { eof_code = e.code; eof_length = e.length; }
-        else { code_of[e.symbol] = e.code; length_of[e.symbol] = e.length; }
+        if (e.symbol == kPseudoEof) { t.eof_code = e.code; t.eof_length = e.length; }
+        else { t.code_of[e.symbol] = e.code; t.length_of[e.symbol] = e.length; }
     }
     out.put(static_cast<uint16_t>(count), 16);
     group_sizes.push_back(static_cast<uint16_t>(count));
@@ -499,10 +509,15 @@ void huffman_encode_with(const SymbolStats& st, const uint16_t* data, size_t n, 
         else for (uint16_t v : group) out.put(v, symbol_bits);
         at += size;
     }
-    size_t payload_bits = 0;
-    for (int l = 0; l < eof_leaf; ++l) payload_bits += freq[l] * static_cast<size_t>(length_of[symbols[l]]);
-    out.put_codes(data, n, code_of.data(), length_of.data(), payload_bits);
-    out.put(eof_code, eof_length);
+    t.payload_bits = 0;
+    for (int l = 0; l < eof_leaf; ++l) t.payload_bits += freq[l] * static_cast<size_t>(t.length_of[symbols[l]]);
+}
+
+void huffman_encode_with(const SymbolStats& st, const uint16_t* data, size_t n, BitWriter& out) {
+    HuffmanTable t;
+    huffman_table(st, n, out, t);
+    out.put_codes(data, n, t.code_of.data(), t.length_of.data(), t.payload_bits);
+    out.put(t.eof_code, t.eof_length);
 }
 }  // namespace
 
@@ -694,6 +709,80 @@ void write_huffman_or_golomb(const uint16_t* data, size_t n, BitWriter& out) {
     }
 }
 
+// writeHuffmanOrGolomb and the run-length wrapper of writeCompressed (:449-453) decided from a stream's statistics alone --
+// the device has counted (mp_entropy.hip) and will write the codes; the host builds the table.  Same decisions, same bits:
+// the Huffman cost is table + sum of count x length + pseudo-EOF, the Golomb cost as in write_huffman_or_golomb.
+void plan_stream(bool rle_flag, bool shorter, uint32_t rle_size, size_t n, uint32_t largest, const uint32_t* triples, size_t distinct,
+                 StreamPlan& plan) {
+    SymbolStats st;
+    st.largest = static_cast<uint16_t>(largest);
+    st.hist.assign(n ? static_cast<size_t>(largest) + 1 : 1, 0);
+    std::vector<std::pair<uint32_t, uint16_t>> by_first(distinct);
+    for (size_t d = 0; d < distinct; ++d) {
+        const uint32_t symbol = triples[3 * d];
+        st.hist[symbol] = triples[3 * d + 1];
+        by_first[d] = {triples[3 * d + 2], static_cast<uint16_t>(symbol)};
+    }
+    std::sort(by_first.begin(), by_first.end());                // order of first appearance (positions are distinct)
+    st.distinct.resize(distinct);
+    for (size_t d = 0; d < distinct; ++d) st.distinct[d] = by_first[d].second;
+
+    plan = StreamPlan();
+    if (rle_flag) {
+        plan.pre.put(shorter ? 1 : 0, 1);
+        if (shorter) plan.pre.put(rle_size, 32);
+    }
+    BitWriter table_bits;
+    HuffmanTable t;
+    huffman_table(st, n, table_bits, t);
+    size_t best = table_bits.bit_size() + t.payload_bits + t.eof_length;
+    int best_m = -1;
+    for (int m = 1; m < 2048; m = (m & 1) ? m + 1 : (m << 1) - 1) {
+        size_t estimate = 16;
+        for (uint16_t s : st.distinct) estimate += static_cast<size_t>(st.hist[s]) * golomb_length(s, static_cast<uint32_t>(m));
+        if (estimate < best) { best = estimate; best_m = m; }
+    }
+    if (best_m < 0) {
+        plan.pre.put(0, 1);
+        plan.pre.append(table_bits);
+        plan.post.put(t.eof_code, t.eof_length);
+        plan.payload_bits = t.payload_bits;
+        plan.mode = 0;
+        plan.max_code_length = t.max_length;
+        plan.entries.reserve(3 * distinct);
+        for (uint16_t s : st.distinct) {
+            plan.entries.push_back(s);
+            plan.entries.push_back(t.code_of[s]);
+            plan.entries.push_back(t.length_of[s]);
+        }
+    } else {
+        plan.pre.put(1, 1);
+        plan.pre.put(static_cast<uint16_t>(best_m), 16);
+        plan.payload_bits = best - 16;
+        plan.mode = 1;
+        plan.m = static_cast<uint32_t>(best_m);
+    }
+}
+
+void or_bits(uint8_t* dst, size_t bit_offset, const BitWriter& piece) {
+    const size_t nbits = piece.bit_size();
+    const uint64_t* src = piece.words();
+    for (size_t done = 0; done < nbits; done += 64) {           // 64 source bits at a time, byte by byte into place
+        const uint64_t word = src[done >> 6];
+        const size_t take = std::min<size_t>(64, nbits - done);
+        size_t at = bit_offset + done;
+        for (size_t k = 0; k < take;) {
+            const size_t byte = at >> 3;
+            const int off = static_cast<int>(at & 7);
+            const int width = static_cast<int>(std::min<size_t>(8 - off, take - k));
+            const uint8_t bits = static_cast<uint8_t>((word >> (64 - k - width)) & ((1u << width) - 1u));
+            dst[byte] |= static_cast<uint8_t>(bits << (8 - off - width));
+            at += static_cast<size_t>(width);
+            k += static_cast<size_t>(width);
+        }
+    }
+}
+
 bool read_huffman_or_golomb(BitReader& in, size_t length, std::vector<uint16_t>& out) {
     if (in.get(1) == 0) return huffman_decode(in, out);
     const uint32_t m = static_cast<uint32_t>(in.get(16));
@@ -816,6 +905,20 @@ void parallel_for(int n, F&& body) {
     WorkerPool::instance().run(n, workers, fn);
 }
 }  // namespace
+
+BitWriter container_head(int width, int height, int K, int block_size, const double* quant) {
+    BitWriter head;
+    head.put(kMagic, 32);
+    head.put(static_cast<uint32_t>(width), 32);
+    head.put(static_cast<uint32_t>(height), 32);
+    head.put(static_cast<uint8_t>(K), 8);
+    head.put(static_cast<uint8_t>(block_size), 8);
+    for (int ch = 0; ch < 3; ++ch)
+        for (int i = 0; i < K; ++i) head.put(static_cast<uint16_t>(quant[ch * K + i]), 16);    // :420 u16 of an integral double
+    return head;
+}
+
+void parallel_jobs(int n, const std::function<void(int)>& body) { parallel_for(n, body); }
 
 std::vector<uint8_t> write_compressed(const Streams& s) {
     const int K = s.K;
@@ -1024,6 +1127,68 @@ uint8_t* encode_symbol_streams_malloc(int width, int height, int K, int block_si
         }
     });
     return concat_malloc(head, parts, nbytes);
+}
+
+// encode_symbol_streams_malloc by the route the device-side entropy stage takes, with the device's share done here on the
+// host: per-stream statistics -> plan_stream -> codes at the planned bit offsets -> OR the pieces into place.  Exists so that
+// the planning half can be checked against the direct route without a GPU (tests/test_host_bitstream.py).
+uint8_t* encode_symbol_streams_by_plan_malloc(int width, int height, int K, int block_size, const double* quant, const uint16_t* counts,
+                                              const uint16_t* symbols, const unsigned long long* off, size_t* nbytes) {
+    const size_t tiles = static_cast<size_t>((width + block_size - 1) / block_size) *
+                         static_cast<size_t>((height + block_size - 1) / block_size);
+    const int S = 6 * K + 1;
+    std::vector<StreamPlan> plans(static_cast<size_t>(S));
+    std::vector<BitWriter> payload(static_cast<size_t>(S));
+    for (int j = 0; j < S; ++j) {
+        const uint16_t* data = j == 0 ? counts : symbols + off[j - 1];
+        const size_t n = j == 0 ? 3 * tiles : static_cast<size_t>(off[j] - off[j - 1]);
+        const size_t rle_size = j == 0 ? n : rle_encoded_size(data, n);
+        const bool shorter = j != 0 && rle_size + 4 < n;
+        const std::vector<uint16_t> packed = shorter ? rle_encode(data, n) : std::vector<uint16_t>();
+        const uint16_t* coded = shorter ? packed.data() : data;
+        const size_t coded_n = shorter ? packed.size() : n;
+        std::vector<uint32_t> hist(65536, 0), first(65536, 0), triples;
+        uint32_t largest = 0;
+        for (size_t i = 0; i < coded_n; ++i) {
+            if (hist[coded[i]]++ == 0) first[coded[i]] = static_cast<uint32_t>(i);
+            largest = std::max<uint32_t>(largest, coded[i]);
+        }
+        for (uint32_t v = 0; v < 65536; ++v)
+            if (hist[v]) { triples.push_back(v); triples.push_back(hist[v]); triples.push_back(first[v]); }
+        StreamPlan& p = plans[static_cast<size_t>(j)];
+        plan_stream(j != 0, shorter, static_cast<uint32_t>(rle_size), coded_n, largest, triples.data(), triples.size() / 3, p);
+        BitWriter& w = payload[static_cast<size_t>(j)];
+        if (p.mode == 0) {
+            std::vector<uint32_t> code_of(static_cast<size_t>(largest) + 1, 0);
+            std::vector<uint8_t> length_of(static_cast<size_t>(largest) + 1, 0);
+            for (size_t k = 0; k < p.entries.size(); k += 3) {
+                code_of[p.entries[k]] = p.entries[k + 1];
+                length_of[p.entries[k]] = static_cast<uint8_t>(p.entries[k + 2]);
+            }
+            w.put_codes(coded, coded_n, code_of.data(), length_of.data(), p.payload_bits);
+        } else {
+            for (size_t i = 0; i < coded_n; ++i) golomb_write(coded[i], p.m, w);
+        }
+        if (w.bit_size() != p.payload_bits) return nullptr;
+    }
+    const BitWriter head = container_head(width, height, K, block_size, quant);
+    size_t total = head.bit_size();
+    for (int j = 0; j < S; ++j) total += plans[static_cast<size_t>(j)].pre.bit_size() + plans[static_cast<size_t>(j)].payload_bits + plans[static_cast<size_t>(j)].post.bit_size();
+    *nbytes = (total + 7) / 8;
+    uint8_t* dst = static_cast<uint8_t*>(std::calloc(*nbytes ? *nbytes : 1, 1));
+    if (!dst) return nullptr;
+    or_bits(dst, 0, head);
+    size_t at = head.bit_size();
+    for (int j = 0; j < S; ++j) {
+        const StreamPlan& p = plans[static_cast<size_t>(j)];
+        or_bits(dst, at, p.pre);
+        at += p.pre.bit_size();
+        or_bits(dst, at, payload[static_cast<size_t>(j)]);
+        at += p.payload_bits;
+        or_bits(dst, at, p.post);
+        at += p.post.bit_size();
+    }
+    return dst;
 }
 
 uint8_t* encode_planar_records_malloc(int width, int height, int K, int block_size, const double* quant, const uint16_t* counts,

@@ -9,6 +9,7 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <functional>
 #include <vector>
 
 namespace mpc {
@@ -95,6 +96,30 @@ uint8_t* encode_planar_records_malloc(int width, int height, int K, int block_si
 // only, step-0 coefficients already difference coded), off[6K + 1] = stream boundaries in symbols
 uint8_t* encode_symbol_streams_malloc(int width, int height, int K, int block_size, const double* quant, const uint16_t* counts,
                                       const uint16_t* symbols, const unsigned long long* off, size_t* nbytes);
+
+// ---- the host's share of the entropy stage when the device does the per-symbol work (mp_entropy.hip) ----
+struct StreamPlan {
+    BitWriter pre;                   // what precedes the stream's codes: run-length flag (+ size), Huffman/Golomb bit, table or M
+    BitWriter post;                  // what follows them: the pseudo-EOF code (Huffman)
+    size_t payload_bits = 0;         // bits of the codes themselves
+    int mode = 0;                    // 0 = Huffman, 1 = Golomb
+    uint32_t m = 0;                  // Golomb parameter
+    int max_code_length = 0;         // Huffman
+    std::vector<uint32_t> entries;   // Huffman: (symbol, code, length) of every symbol that occurs
+};
+// One stream of the container from its statistics: n coded symbols (after run-length coding if `shorter`), `largest` of them,
+// triples[3 * distinct] = (symbol, count, position of first appearance) in any order.  rle_flag: false for `lengths`.
+void plan_stream(bool rle_flag, bool shorter, uint32_t rle_size, size_t n, uint32_t largest, const uint32_t* triples, size_t distinct,
+                 StreamPlan& plan);
+BitWriter container_head(int width, int height, int K, int block_size, const double* quant /*[3*K]*/);
+// dst |= piece, MSB first, at bit_offset (dst: the container's bytes)
+void or_bits(uint8_t* dst, size_t bit_offset, const BitWriter& piece);
+// body(0..n-1) on the entropy stage's worker pool
+void parallel_jobs(int n, const std::function<void(int)>& body);
+
+// encode_symbol_streams_malloc through plan_stream / or_bits, the device's share (statistics, code writing) done on the host
+uint8_t* encode_symbol_streams_by_plan_malloc(int width, int height, int K, int block_size, const double* quant, const uint16_t* counts,
+                                              const uint16_t* symbols, const unsigned long long* off, size_t* nbytes);
 
 // Inverse of assemble_streams: per-tile records in the reference's visiting order.  counts[3*tiles],
 // choices[3*tiles*K] (deltaId | intCoeff << 16, zero beyond count).  false = streams inconsistent with `lengths`.

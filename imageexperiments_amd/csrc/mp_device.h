@@ -193,6 +193,60 @@ struct StreamArgs {
 size_t stream_workspace_words(long long tiles, int K);
 int launch_stream_assembly(const StreamArgs& a, void* stream);
 
+// ---- device-side entropy stage (mp_entropy.hip): everything that touches every symbol of the 1 + 6K streams ----
+constexpr int kEntBlock = 4096;         // symbols per scan block
+constexpr int kEntHistSpan = 4;         // scan blocks per histogram block
+constexpr int kEntMaxStreams = 6 * kMaxDeviceK + 1;
+
+struct EntStream {                      // one per stream; the device fills the first part, the host the second
+    unsigned long long raw_off;         // first symbol of the stream in `symbols` (stream 0 = `lengths`: the counts array)
+    unsigned n;                         // symbols of the stream as assembled
+    unsigned blk_begin, hblk_begin;     // first scan block / histogram block
+    unsigned rle_size;                  // symbols runLengthEncode emits (Huffman.cpp:246-279)
+    unsigned shorter;                   // 1 = the run-length coded stream is what gets coded (CompressedImage.cpp:450)
+    unsigned eff_n;                     // symbols that get coded
+    unsigned largest;                   // largest of them
+    unsigned distinct, triple_off;      // its (symbol, count, first position) triples in `triples`
+    unsigned mode;                      // host: 0 = Huffman (dense table), 1 = Golomb
+    unsigned m;                         // host: Golomb parameter
+    unsigned reserved;
+    unsigned long long bit_off;         // host: bit offset of the stream's first code in the container
+    unsigned long long coded_bits;      // device: bits written for the stream's symbols
+};
+
+struct EntropyArgs {
+    const uint16_t* counts;             // [n_lengths] the lengths stream
+    const uint16_t* symbols;            // the 6K code streams back to back (StreamArgs::symbols)
+    const unsigned long long* stream_off;   // [6K + 1]
+    unsigned n_lengths;
+    int n_streams;                      // 6K + 1
+    uint16_t* packed;                   // run-length coded streams, at the offsets of their sources (capacity of `symbols`)
+    EntStream* streams;                 // [n_streams]
+    unsigned* totals;                   // [4]: scan blocks, histogram blocks, triples written, triple overflow flag
+    unsigned* blk_lead;                 // per scan block: symbols in front of its first run start | run ends there << 31
+    unsigned* blk_inner;                // ... run-length symbols emitted for the runs that start inside the block
+    unsigned* blk_tail;                 // ... symbols from its last run start to its end
+    unsigned* blk_carry;                // ... symbols of the run its first symbol continues, in front of the block
+    unsigned* blk_out;                  // ... first run-length symbol of the block in the packed stream
+    unsigned* blk_bits;                 // ... code bits
+    unsigned long long* blk_bit_off;    // ... bit offset of its first code in the container
+    unsigned* ghist;                    // [n_streams][65536] zero between calls
+    unsigned* gfirst;                   // [n_streams][65536] 0xFFFFFFFF between calls
+    unsigned* triples;                  // [triple_cap][3]
+    unsigned triple_cap;
+    unsigned* tcode;                    // [n_streams][65536] zero between calls
+    uint8_t* tlen;                      // [n_streams][65536]
+    const unsigned* entries;            // [n_entries][3]: stream << 16 | symbol, code, length
+    unsigned n_entries;
+    unsigned* out32;                    // the container, zeroed
+    unsigned long long out_words;
+};
+size_t entropy_max_blocks(unsigned long long symbols, int n_streams);
+// capacity_symbols: upper bound of the symbols in all streams (lengths included); hipError_t as int
+int launch_entropy_phase1(const EntropyArgs& a, unsigned long long capacity_symbols, void* stream);
+// raw_symbols: symbols in all streams as assembled (sum of EntStream::n)
+int launch_entropy_phase2(const EntropyArgs& a, unsigned long long raw_symbols, void* stream);
+
 // choices[tiles][3][K] -> planar[3][K][tiles] (what the host entropy stage of mpc_encode_image(s) reads); hipError_t as int
 int launch_planar_records(const uint32_t* choices, uint32_t* planar, long long tiles, int K, void* stream);
 

@@ -1,0 +1,561 @@
+// mp_entropy.hip -- product: the per-symbol work of the entropy stage on the device (SURVEY 8f N2:
+// "RLE, Golomb/Huffman bit-length costing from histograms", CompressedImage.cpp:359-458).
+//
+// The container's 1 + 6K streams (`lengths`, then codes[0..6K)) are coded independently: run-length coded if that is
+// shorter (:449-453, Huffman.cpp:246-279), then Huffman or Golomb, whichever is shorter (:359-390).  Everything that
+// touches every symbol runs here; the host keeps what is sequential and small -- one Huffman tree per stream, built from
+// the stream's histogram and the order in which its symbols first appear (that order decides the reference's ties, see
+// host_bitstream.cpp: MsvcHashOrder) -- and hands back one code table per stream.
+//
+//   phase 1 (after stream assembly, same stream)
+//     layout   sizes and block tables of the 1 + 6K streams (from the stream offsets, which only the device knows)
+//     runs     per block of 4096 symbols: where runs of equal symbols start and end; symbols runLengthEncode emits for
+//              every run that starts inside the block
+//     plan     per stream: the run a block continues (a segmented scan over the blocks), symbols emitted for those in
+//              closed form, output offsets, the reference's decision `packed.size() + 4 < stream.size()`
+//     pack     the run-length coded stream, for the streams where it is shorter
+//     hist     histogram and first position of every symbol of the stream that will be coded (LDS for symbols < 8192)
+//     compact  (symbol, count, first position) of the symbols that occur, per stream, in one list for the host
+//   host: Huffman tables / Golomb parameter, bit offsets of every stream's payload in the container
+//   phase 2
+//     tables   scatter the (symbol -> code, length) entries into dense per-stream tables
+//     count    code bits per block;  offsets  exclusive scan per stream, from the stream's bit offset
+//     write    the codes, MSB first, into the zeroed container (32-bit atomic ORs of byte-swapped words)
+//     clear    the table entries, for the next frame
+// Integer work, HBM/L2-bound; 2 bytes per symbol and pass, ~10 M symbols per 16 Mpixel frame.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mp_device.h"
+
+namespace mpc {
+
+namespace {
+constexpr int kThreads = 256;
+constexpr int kPer = kEntBlock / kThreads;              // 16 consecutive symbols per thread
+constexpr unsigned kChunk = 0x8001u;                    // a run is cut after this many symbols (Huffman.cpp:262-267)
+constexpr int kLdsBins = 8192;
+constexpr unsigned kNoPos = 0xFFFFFFFFu;
+static_assert(kPer * kThreads == kEntBlock, "block shape");
+
+__device__ __forceinline__ const uint16_t* raw_stream(const EntropyArgs& a, int j, const EntStream& s)
+{
+    return j == 0 ? a.counts : a.symbols + s.raw_off;
+}
+
+// stream of scan block / histogram block `b`: the last j with begin[j] <= b (begin is non-decreasing)
+template <bool kHist>
+__device__ __forceinline__ int find_stream(const EntropyArgs& a, unsigned b)
+{
+    int lo = 0, hi = a.n_streams - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        const unsigned begin = kHist ? a.streams[mid].hblk_begin : a.streams[mid].blk_begin;
+        if (begin <= b) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ unsigned wave_incl_add(unsigned v)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned o = __shfl_up(v, d);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+// exclusive prefix sum over the 256 threads of a block; *total = block sum.  `scratch`: 4 words of LDS.
+__device__ __forceinline__ unsigned block_excl_add(unsigned v, unsigned* scratch, unsigned* total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned incl = wave_incl_add(v);
+    __syncthreads();                                     // scratch may still be read from an earlier call
+    if (lane == 63) scratch[wave] = incl;
+    __syncthreads();
+    unsigned before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < kThreads / 64; ++w) {
+        const unsigned t = scratch[w];
+        if (w < wave) before += t;
+        all += t;
+    }
+    *total = all;
+    return before + incl - v;
+}
+
+// symbols runLengthEncode emits at offset c of a chunk, when the symbol there is / is not the last of its maximal run
+__device__ __forceinline__ unsigned rle_emitted(unsigned c, bool run_end)
+{
+    return (c == 0) + (c == 1) + ((c >= 1) && (run_end || c == kChunk - 1));
+}
+
+// number of p in [0, x) with p mod kChunk == r
+__device__ __forceinline__ unsigned residues_below(unsigned x, unsigned r) { return (x + kChunk - 1 - r) / kChunk; }
+
+// symbols emitted for offsets [p0, p0 + len) of one run, the last of which ends the run or not
+__device__ __forceinline__ unsigned rle_emitted_span(unsigned p0, unsigned len, bool run_end)
+{
+    if (len == 0) return 0;
+    const unsigned hi = p0 + len;
+    unsigned e = (residues_below(hi, 0) - residues_below(p0, 0)) + (residues_below(hi, 1) - residues_below(p0, 1)) +
+                 (residues_below(hi, kChunk - 1) - residues_below(p0, kChunk - 1));
+    const unsigned c = (hi - 1) % kChunk;
+    if (run_end && c >= 1 && c != kChunk - 1) ++e;
+    return e;
+}
+}  // namespace
+
+// ---- phase 1 ----
+__global__ __launch_bounds__(kThreads) void ent_layout_kernel(const EntropyArgs a)
+{
+    __shared__ unsigned nblk[kEntMaxStreams], nhblk[kEntMaxStreams];
+    const int j = threadIdx.x;
+    if (j < a.n_streams) {
+        const unsigned long long begin = j == 0 ? 0ULL : a.stream_off[j - 1];
+        const unsigned n = j == 0 ? a.n_lengths : (unsigned)(a.stream_off[j] - begin);
+        EntStream s{};
+        s.raw_off = begin;
+        s.n = n;
+        s.eff_n = n;
+        a.streams[j] = s;
+        nblk[j] = (n + kEntBlock - 1) / kEntBlock;
+        nhblk[j] = (n + kEntHistSpan * kEntBlock - 1) / (kEntHistSpan * kEntBlock);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned b = 0, h = 0;
+        for (int s = 0; s < a.n_streams; ++s) {
+            a.streams[s].blk_begin = b;
+            a.streams[s].hblk_begin = h;
+            b += nblk[s];
+            h += nhblk[s];
+        }
+        a.totals[0] = b;
+        a.totals[1] = h;
+        a.totals[2] = 0;                                  // triples written
+        a.totals[3] = 0;                                  // overflow flag
+    }
+}
+
+// kPack = false: per-block run structure;  kPack = true: write the run-length coded stream (offsets from the plan)
+template <bool kPack>
+__global__ __launch_bounds__(kThreads) void ent_runs_kernel(const EntropyArgs a)
+{
+    __shared__ unsigned scratch[kThreads / 64];
+    __shared__ int first_bnd, last_bnd;
+    __shared__ unsigned inner_sum;
+    const unsigned b = blockIdx.x;
+    if (b >= a.totals[0]) return;
+    const int j = find_stream<false>(a, b);
+    const EntStream s = a.streams[j];
+    if (j == 0) {                                         // `lengths` is never run-length coded (CompressedImage.cpp:424)
+        if (!kPack && threadIdx.x == 0) {
+            a.blk_lead[b] = 0;
+            a.blk_inner[b] = 0;
+            a.blk_tail[b] = 0;
+        }
+        return;
+    }
+    if (kPack && !s.shorter) return;
+    const unsigned lb = b - s.blk_begin;
+    const unsigned begin = lb * kEntBlock, len = min((unsigned)kEntBlock, s.n - begin);
+    const uint16_t* src = raw_stream(a, j, s);
+    if (threadIdx.x == 0) {
+        first_bnd = (int)len;
+        last_bnd = -1;
+        inner_sum = 0;
+    }
+    // the thread's symbols with one neighbour on either side
+    const unsigned t0 = threadIdx.x * kPer;
+    uint16_t v[kPer + 2];
+#pragma unroll
+    for (int k = 0; k < kPer + 2; ++k) {
+        const long long gi = (long long)begin + t0 + k - 1;
+        v[k] = (gi >= 0 && gi < (long long)s.n && t0 + k <= len + 1) ? src[gi] : (uint16_t)0;
+    }
+    unsigned bnd_mask = 0, end_mask = 0;                  // bit k: position t0 + k starts / ends a maximal run
+    int my_last = -1;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+        const unsigned i = t0 + k, gi = begin + i;
+        if (i < len) {
+            if (gi == 0 || v[k + 1] != v[k]) { bnd_mask |= 1u << k; my_last = (int)i; }
+            if (gi == s.n - 1 || v[k + 2] != v[k + 1]) end_mask |= 1u << k;
+        }
+    }
+    __syncthreads();
+    if (bnd_mask) {
+        atomicMin(&first_bnd, (int)(t0 + (unsigned)__builtin_ctz(bnd_mask)));
+        atomicMax(&last_bnd, my_last);
+    }
+    // start of the run that reaches into this thread's range: the last boundary of any earlier thread (max scan)
+    int start = my_last;
+    {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(start, d);
+            if (lane >= d) start = max(start, o);
+        }
+        __shared__ int wave_last[kThreads / 64];
+        if (lane == 63) wave_last[wave] = start;
+        int excl = __shfl_up(start, 1);
+        if (lane == 0) excl = -1;
+        __syncthreads();
+        for (int w = 0; w < wave; ++w) excl = max(excl, wave_last[w]);
+        start = excl;
+    }
+    const unsigned carry = kPack ? a.blk_carry[b] : 0u;   // symbols of the run in front of the block (lead positions only)
+    unsigned emitted = 0;
+    unsigned e_of[kPer];
+    {
+        int cur = start;
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const unsigned i = t0 + k;
+            e_of[k] = 0;
+            if (i < len) {
+                if (bnd_mask & (1u << k)) cur = (int)i;
+                if (cur >= 0 || kPack) {
+                    const unsigned p = cur >= 0 ? i - (unsigned)cur : carry + i;
+                    e_of[k] = rle_emitted(p % kChunk, (end_mask >> k) & 1u);
+                    emitted += e_of[k];
+                }
+            }
+        }
+    }
+    if (!kPack) {
+        const unsigned w = wave_incl_add(emitted);
+        if ((threadIdx.x & 63) == 63 && w) atomicAdd(&inner_sum, w);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned lead = (unsigned)first_bnd;    // positions in front of the block's first boundary
+            unsigned lead_end = 0;
+            if (lead > 0) {
+                const unsigned gi = begin + lead - 1;
+                lead_end = (gi == s.n - 1) || (gi + 1 < s.n && src[gi + 1] != src[gi]);
+            }
+            a.blk_lead[b] = lead | (lead_end << 31);
+            a.blk_inner[b] = inner_sum;
+            a.blk_tail[b] = last_bnd >= 0 ? len - (unsigned)last_bnd : 0u;
+        }
+        return;
+    }
+    unsigned total;
+    unsigned at = a.blk_out[b] + block_excl_add(emitted, scratch, &total);
+    uint16_t* dst = a.packed + s.raw_off;
+    {
+        int cur = start;
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const unsigned i = t0 + k;
+            if (i < len) {
+                if (bnd_mask & (1u << k)) cur = (int)i;
+                const unsigned p = cur >= 0 ? i - (unsigned)cur : carry + i;
+                const unsigned c = p % kChunk;
+                if (c <= 1) dst[at++] = v[k + 1];
+                if (c >= 1 && (((end_mask >> k) & 1u) || c == kChunk - 1)) dst[at++] = (uint16_t)(c - 1);
+            }
+        }
+    }
+}
+
+// one wave per stream
+__global__ __launch_bounds__(64) void ent_rle_plan_kernel(const EntropyArgs a)
+{
+    const int j = blockIdx.x, lane = threadIdx.x;
+    EntStream s = a.streams[j];
+    const unsigned nb = (s.n + kEntBlock - 1) / kEntBlock;
+    unsigned run_before = 0;                              // length of the run that ends with the last symbol before this chunk
+    unsigned out_before = 0;
+    for (unsigned base = 0; base < nb; base += 64) {
+        const unsigned lb = base + lane;
+        const bool in = lb < nb;
+        const unsigned b = s.blk_begin + (in ? lb : 0);
+        const unsigned len = in ? min((unsigned)kEntBlock, s.n - lb * kEntBlock) : 0u;
+        const unsigned lead_word = in ? a.blk_lead[b] : 0u;
+        const unsigned lead = lead_word & 0x7FFFFFFFu;
+        const bool lead_end = lead_word >> 31;
+        const unsigned inner = in ? a.blk_inner[b] : 0u;
+        const unsigned tail = in ? a.blk_tail[b] : 0u;
+        // tail_run[b] = a boundary inside the block ? tail : tail_run[b - 1] + len   (segmented inclusive scan)
+        unsigned val = (lead < len) ? tail : len;
+        bool reset = (lead < len) || !in;
+        if (!in) val = 0;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned ov = __shfl_up(val, d);
+            const int orr = __shfl_up((int)reset, d);
+            if (lane >= d && !reset) { val += ov; reset = orr != 0; }
+        }
+        if (!reset) val += run_before;                    // no boundary since the start of this chunk of blocks
+        unsigned prev_run = __shfl_up(val, 1);
+        if (lane == 0) prev_run = run_before;
+        const unsigned carry = lead > 0 ? prev_run : 0u;
+        const unsigned emit = inner + rle_emitted_span(carry, lead, lead_end);
+        const unsigned incl = wave_incl_add(in ? emit : 0u);
+        if (in) {
+            a.blk_carry[b] = carry;
+            a.blk_out[b] = out_before + incl - emit;
+        }
+        out_before += __shfl(incl, 63);
+        run_before = __shfl(val, (int)min(63u, nb - 1 - base));
+    }
+    if (lane == 0) {
+        s.rle_size = out_before;
+        s.shorter = (j != 0 && (unsigned long long)out_before + 4ULL < s.n) ? 1u : 0u;      // CompressedImage.cpp:450
+        s.eff_n = s.shorter ? out_before : s.n;
+        a.streams[j] = s;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void ent_hist_kernel(const EntropyArgs a)
+{
+    __shared__ unsigned hist[kLdsBins], first[kLdsBins];
+    const unsigned hb = blockIdx.x;
+    if (hb >= a.totals[1]) return;
+    const int j = find_stream<true>(a, hb);
+    const EntStream s = a.streams[j];
+    const unsigned begin = (hb - s.hblk_begin) * (kEntHistSpan * kEntBlock);
+    if (begin >= s.eff_n) return;
+    const unsigned end = min(s.eff_n, begin + kEntHistSpan * kEntBlock);
+    const uint16_t* src = s.shorter ? a.packed + s.raw_off : raw_stream(a, j, s);
+    for (int i = threadIdx.x; i < kLdsBins; i += kThreads) {
+        hist[i] = 0;
+        first[i] = kNoPos;
+    }
+    __syncthreads();
+    unsigned* ghist = a.ghist + (size_t)j * 65536;
+    unsigned* gfirst = a.gfirst + (size_t)j * 65536;
+    unsigned largest = 0;
+    for (unsigned i = begin + threadIdx.x; i < end; i += kThreads) {
+        const unsigned sym = src[i];
+        largest = max(largest, sym);
+        if (sym < kLdsBins) {
+            atomicAdd(&hist[sym], 1u);
+            atomicMin(&first[sym], i);
+        } else {
+            atomicAdd(&ghist[sym], 1u);
+            atomicMin(&gfirst[sym], i);
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) largest = max(largest, (unsigned)__shfl_xor((int)largest, d));
+    if ((threadIdx.x & 63) == 0) atomicMax(&a.streams[j].largest, largest);
+    __syncthreads();
+    for (int i = threadIdx.x; i < kLdsBins; i += kThreads) {
+        const unsigned h = hist[i];
+        if (h) {
+            atomicAdd(&ghist[i], h);
+            atomicMin(&gfirst[i], first[i]);
+        }
+    }
+}
+
+// one workgroup per stream: the bins that occur -> (symbol, count, first position), ascending symbols; bins reset
+__global__ __launch_bounds__(kThreads) void ent_compact_kernel(const EntropyArgs a)
+{
+    __shared__ unsigned scratch[kThreads / 64];
+    __shared__ unsigned base_at;
+    const int j = blockIdx.x;
+    const EntStream s = a.streams[j];
+    unsigned* ghist = a.ghist + (size_t)j * 65536;
+    unsigned* gfirst = a.gfirst + (size_t)j * 65536;
+    const unsigned bins = s.eff_n ? s.largest + 1 : 0;
+    unsigned mine = 0;
+    for (unsigned i = threadIdx.x; i < bins; i += kThreads) mine += ghist[i] != 0;
+    unsigned distinct;
+    block_excl_add(mine, scratch, &distinct);
+    if (threadIdx.x == 0) {
+        const unsigned at = atomicAdd(&a.totals[2], distinct);
+        base_at = at;
+        a.streams[j].distinct = distinct;
+        a.streams[j].triple_off = at;
+        if (at + distinct > a.triple_cap) a.totals[3] = 1;
+    }
+    __syncthreads();
+    const bool room = base_at + distinct <= a.triple_cap;
+    unsigned run = base_at;
+    for (unsigned i0 = 0; i0 < bins; i0 += kThreads) {
+        const unsigned i = i0 + threadIdx.x;
+        const unsigned h = i < bins ? ghist[i] : 0u;
+        unsigned total;
+        const unsigned rank = block_excl_add(h != 0, scratch, &total);
+        if (h) {
+            if (room) {
+                unsigned* t = a.triples + 3 * (size_t)(run + rank);
+                t[0] = i;
+                t[1] = h;
+                t[2] = gfirst[i];
+            }
+            ghist[i] = 0;
+            gfirst[i] = kNoPos;
+        }
+        run += total;
+    }
+}
+
+// ---- phase 2 ----
+__global__ __launch_bounds__(kThreads) void ent_tables_kernel(const EntropyArgs a, int clear)
+{
+    const unsigned e = blockIdx.x * kThreads + threadIdx.x;
+    if (e >= a.n_entries) return;
+    const unsigned key = a.entries[3 * (size_t)e];        // stream << 16 | symbol
+    if (clear) {
+        a.tcode[key] = 0;
+        a.tlen[key] = 0;
+    } else {
+        a.tcode[key] = a.entries[3 * (size_t)e + 1];
+        a.tlen[key] = (uint8_t)a.entries[3 * (size_t)e + 2];
+    }
+}
+
+namespace {
+__device__ __forceinline__ unsigned bit_width_u32(unsigned v) { return v ? 32u - (unsigned)__builtin_clz(v) : 0u; }
+
+// BitBuffer.cpp:228-269, the reference's own Golomb variant
+__device__ __forceinline__ unsigned golomb_bits(unsigned value, unsigned m, unsigned b, unsigned limit)
+{
+    const unsigned q = value / m, rem = value - q * m;
+    return b + q + 1 + (rem < limit ? 0u : 1u);
+}
+}  // namespace
+
+// kWrite = false: code bits per block;  kWrite = true: the codes themselves
+template <bool kWrite>
+__global__ __launch_bounds__(kThreads) void ent_code_kernel(const EntropyArgs a)
+{
+    __shared__ unsigned scratch[kThreads / 64];
+    const unsigned b = blockIdx.x;
+    if (b >= a.totals[0]) return;
+    const int j = find_stream<false>(a, b);
+    const EntStream s = a.streams[j];
+    const unsigned begin = (b - s.blk_begin) * kEntBlock;
+    if (begin >= s.eff_n) {
+        if (!kWrite && threadIdx.x == 0) a.blk_bits[b] = 0;
+        return;
+    }
+    const unsigned len = min((unsigned)kEntBlock, s.eff_n - begin);
+    const uint16_t* src = (s.shorter ? a.packed + s.raw_off : raw_stream(a, j, s)) + begin;
+    const unsigned t0 = threadIdx.x * kPer;
+    const bool golomb = s.mode != 0;
+    const unsigned m = golomb ? s.m : 1u;
+    const unsigned gb = bit_width_u32(m), glimit = (1u << (gb + 1)) - m;
+    const unsigned* tcode = a.tcode + (size_t)j * 65536;
+    const uint8_t* tlen = a.tlen + (size_t)j * 65536;
+    unsigned sym[kPer], bits = 0;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+        sym[k] = 0;
+        if (t0 + k < len) {
+            sym[k] = src[t0 + k];
+            bits += golomb ? golomb_bits(sym[k], m, gb, glimit) : (unsigned)tlen[sym[k]];
+        }
+    }
+    unsigned total;
+    const unsigned before = block_excl_add(bits, scratch, &total);
+    if (!kWrite) {
+        if (threadIdx.x == 0) a.blk_bits[b] = total;
+        return;
+    }
+    if (bits == 0) return;
+    // MSB-first bit position P lives in byte P >> 3; a 32-bit big-endian word is OR-ed in byte-swapped
+    unsigned long long pos = a.blk_bit_off[b] + before;
+    unsigned long long w = pos >> 5;
+    unsigned fill = (unsigned)(pos & 31), acc = 0;
+    auto flush = [&]() {
+        if (acc && w < a.out_words) atomicOr(a.out32 + w, __builtin_bswap32(acc));
+    };
+    auto append = [&](unsigned code, unsigned n) {        // n in 1..32, code < 2^n
+        const unsigned room = 32 - fill;
+        if (n < room) {
+            acc |= code << (room - n);
+            fill += n;
+        } else {
+            const unsigned rest = n - room;
+            acc |= code >> rest;
+            flush();
+            ++w;
+            acc = rest ? code << (32 - rest) : 0u;
+            fill = rest;
+        }
+    };
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+        if (t0 + k < len) {
+            if (!golomb) {
+                const unsigned n = tlen[sym[k]];
+                if (n) append(tcode[sym[k]], n);
+            } else {
+                unsigned q = sym[k] / m;
+                const unsigned rem = sym[k] - q * m;
+                while (q >= 32) { append(0xFFFFFFFFu, 32); q -= 32; }
+                append(((1u << q) - 1u) << 1, q + 1);     // q ones and the terminating zero
+                if (rem < glimit) { if (gb) append(rem, gb); }
+                else append(rem + glimit, gb + 1);
+            }
+        }
+    }
+    flush();
+}
+
+// one wave per stream: bit offset of every block's codes
+__global__ __launch_bounds__(64) void ent_bit_offsets_kernel(const EntropyArgs a)
+{
+    const int j = blockIdx.x, lane = threadIdx.x;
+    const EntStream s = a.streams[j];
+    const unsigned nb = (s.eff_n + kEntBlock - 1) / kEntBlock;
+    unsigned long long at = s.bit_off;
+    for (unsigned base = 0; base < nb; base += 64) {
+        const unsigned lb = base + lane;
+        const unsigned bits = lb < nb ? a.blk_bits[s.blk_begin + lb] : 0u;
+        unsigned long long incl = bits;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned long long o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        if (lb < nb) a.blk_bit_off[s.blk_begin + lb] = at + incl - bits;
+        at += __shfl(incl, 63);
+    }
+    if (lane == 0) a.streams[j].coded_bits = at - s.bit_off;
+}
+
+size_t entropy_max_blocks(unsigned long long capacity_symbols, int n_streams)
+{
+    return (size_t)((capacity_symbols + kEntBlock - 1) / kEntBlock) + (size_t)n_streams;
+}
+
+int launch_entropy_phase1(const EntropyArgs& a, unsigned long long capacity_symbols, void* stream_)
+{
+    hipStream_t st = static_cast<hipStream_t>(stream_);
+    if (a.n_streams < 1 || a.n_streams > kEntMaxStreams) return (int)hipErrorInvalidValue;
+    const unsigned blocks = (unsigned)entropy_max_blocks(capacity_symbols, a.n_streams);
+    const unsigned hblocks = (unsigned)((capacity_symbols + kEntHistSpan * kEntBlock - 1) / (kEntHistSpan * kEntBlock)) + (unsigned)a.n_streams;
+    hipLaunchKernelGGL(ent_layout_kernel, dim3(1), dim3(kThreads), 0, st, a);
+    hipLaunchKernelGGL(ent_runs_kernel<false>, dim3(blocks), dim3(kThreads), 0, st, a);
+    hipLaunchKernelGGL(ent_rle_plan_kernel, dim3((unsigned)a.n_streams), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(ent_runs_kernel<true>, dim3(blocks), dim3(kThreads), 0, st, a);
+    hipLaunchKernelGGL(ent_hist_kernel, dim3(hblocks), dim3(kThreads), 0, st, a);
+    hipLaunchKernelGGL(ent_compact_kernel, dim3((unsigned)a.n_streams), dim3(kThreads), 0, st, a);
+    return (int)hipGetLastError();
+}
+
+int launch_entropy_phase2(const EntropyArgs& a, unsigned long long raw_symbols, void* stream_)
+{
+    hipStream_t st = static_cast<hipStream_t>(stream_);
+    if (a.n_streams < 1 || a.n_streams > kEntMaxStreams) return (int)hipErrorInvalidValue;
+    const unsigned blocks = (unsigned)entropy_max_blocks(raw_symbols, a.n_streams);
+    const unsigned eblocks = (a.n_entries + kThreads - 1) / kThreads;
+    if (eblocks) hipLaunchKernelGGL(ent_tables_kernel, dim3(eblocks), dim3(kThreads), 0, st, a, 0);
+    hipLaunchKernelGGL(ent_code_kernel<false>, dim3(blocks), dim3(kThreads), 0, st, a);
+    hipLaunchKernelGGL(ent_bit_offsets_kernel, dim3((unsigned)a.n_streams), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(ent_code_kernel<true>, dim3(blocks), dim3(kThreads), 0, st, a);
+    if (eblocks) hipLaunchKernelGGL(ent_tables_kernel, dim3(eblocks), dim3(kThreads), 0, st, a, 1);
+    return (int)hipGetLastError();
+}
+
+}  // namespace mpc

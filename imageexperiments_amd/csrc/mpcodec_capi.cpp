@@ -214,6 +214,17 @@ struct mpc_context {
     int pipes_cap = 0;                               // > 0: at most this many concurrent sub-batches per call
     hipEvent_t seq_events[kSeqSlots][3] = {};
     hipStream_t seq_down[kSeqSlots] = {};             // one download stream per slot: its worker thread drives it
+    // device-side entropy stage (mp_entropy.hip): per-slot buffers (grow-only) and the histogram tables all slots share
+    // (phase 1 of every frame runs on one stream, in order)
+    struct EntropySlot {
+        void* dev = nullptr;
+        size_t dev_bytes = 0;
+        void* host = nullptr;                        // pinned
+        size_t host_bytes = 0;
+    };
+    EntropySlot ent[kSeqSlots];
+    unsigned* ent_hist = nullptr;                    // ghist | gfirst, [n_streams][65536] each
+    int ent_hist_streams = 0;
     // The pursuit of a call is cut into sub-batches that run on `pipes` internal streams, each with its own
     // workspace: the latency-bound bookkeeping kernels of one sub-batch (finish, update, bucket, fill) overlap
     // the machine-filling sweeps of the other.  Fork/join with events on the caller's stream: still no host
@@ -550,6 +561,11 @@ void mpc_context_destroy(mpc_context* c) {
         (void)hipFree(c->d_flag);
         (void)hipFree(c->stage);
         if (c->host_stage) (void)hipHostFree(c->host_stage);
+        for (auto& e : c->ent) {
+            if (e.dev) (void)hipFree(e.dev);
+            if (e.host) (void)hipHostFree(e.host);
+        }
+        if (c->ent_hist) (void)hipFree(c->ent_hist);
         if (c->seq_up) (void)hipStreamDestroy(c->seq_up);
         if (c->seq_compute) (void)hipStreamDestroy(c->seq_compute);
         for (hipStream_t sd : c->seq_down)
@@ -948,6 +964,19 @@ mpc_status mpc_assemble_symbol_streams(int width, int height, int K, int block_s
     });
 }
 
+mpc_status mpc_assemble_symbol_streams_by_plan(int width, int height, int K, int block_size, const double* quant, const uint16_t* counts,
+                                               const uint16_t* symbols, const unsigned long long* stream_off, uint8_t** bytes, size_t* nbytes) {
+    return guarded([&]() -> mpc_status {
+    if (!quant || !counts || (!symbols && stream_off && stream_off[6 * K]) || !stream_off || !bytes || !nbytes || K < 1 || K > MPC_MAX_K ||
+        block_size < 1 || width < 1 || height < 1)
+        return fail(MPC_ERR_ARGUMENT, "bad argument");
+    for (int s = 0; s < 6 * K; ++s)
+        if (stream_off[s + 1] < stream_off[s]) return fail(MPC_ERR_ARGUMENT, "stream offsets must not decrease");
+    *bytes = mpc::encode_symbol_streams_by_plan_malloc(width, height, K, block_size, quant, counts, symbols, stream_off, nbytes);
+    return *bytes ? MPC_OK : fail(MPC_ERR_ALLOC, "out of memory or inconsistent plan");
+    });
+}
+
 mpc_status mpc_read_compressed(const uint8_t* bytes, size_t nbytes, mpc_streams** out) {
     return guarded([&]() -> mpc_status {
     if (!bytes || !out) return fail(MPC_ERR_ARGUMENT, "null argument");
@@ -1101,6 +1130,195 @@ mpc_status mpc_elias_fano_decode(const uint8_t* bytes, size_t nbytes, size_t n, 
     return MPC_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Entropy stage with the per-symbol work on the device (mp_entropy.hip).  Phase 1 is enqueued behind the stream assembly;
+// a worker then fetches the per-stream statistics, builds the tables (host_bitstream.cpp: plan_stream), sends them back and
+// runs phase 2, which writes the codes into the container on the device; only the finished bytes cross PCIe.
+// MPC_HOST_ENTROPY=1 keeps the whole stage on the host (the symbols cross instead); the same route is taken when a stream
+// is outside what the device tables hold (more distinct symbols than the triple list, a code longer than 32 bits).
+// ------------------------------------------------------------------------------------------------
+namespace {
+constexpr unsigned kTripleCap = 1u << 20;
+
+bool host_entropy_forced() {
+    static const bool forced = env_int("MPC_HOST_ENTROPY", 0) != 0;
+    return forced;
+}
+
+struct EntropyBuffers {
+    mpc::EntropyArgs args{};
+    unsigned* d_entries = nullptr;
+    uint8_t* d_out = nullptr;
+    size_t out_capacity = 0;             // bytes, device and host
+    unsigned long long capacity_symbols = 0;
+    // pinned
+    mpc::EntStream* h_streams = nullptr;
+    unsigned* h_totals = nullptr;
+    unsigned* h_triples = nullptr;
+    unsigned* h_entries = nullptr;
+    uint8_t* h_out = nullptr;
+};
+
+// carve (and grow) slot `sl`'s buffers for frames of `tiles` tiles; the symbols of the streams live in the caller's buffers
+mpc_status entropy_buffers(mpc_context* c, int sl, size_t tiles, int K, EntropyBuffers* b) {
+    auto up = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
+    const int S = 6 * K + 1;
+    const size_t n_tc = 3 * tiles;
+    const unsigned long long cap_symbols = n_tc + 2ULL * n_tc * K;
+    const size_t blocks = mpc::entropy_max_blocks(cap_symbols, S);
+    const size_t streams_b = up(sizeof(mpc::EntStream) * S), totals_b = up(4 * sizeof(unsigned));
+    const size_t blk_u32 = up(sizeof(unsigned) * blocks), blk_u64 = up(sizeof(unsigned long long) * blocks);
+    const size_t triples_b = up(sizeof(unsigned) * 3 * kTripleCap);
+    const size_t packed_b = up(sizeof(uint16_t) * 2 * n_tc * K);
+    const size_t tcode_b = up(sizeof(unsigned) * 65536 * S), tlen_b = up(65536 * static_cast<size_t>(S));
+    const size_t out_b = up(packed_b + 65536);
+    const size_t dev_need = streams_b + totals_b + 6 * blk_u32 + blk_u64 + 2 * triples_b + packed_b + tcode_b + tlen_b + out_b;
+    const size_t host_need = streams_b + totals_b + 2 * triples_b + out_b;
+    mpc_context::EntropySlot& e = c->ent[sl];
+    if (dev_need > e.dev_bytes) {
+        HIP_TRY(hipDeviceSynchronize());
+        if (e.dev) (void)hipFree(e.dev);
+        e.dev = nullptr;
+        e.dev_bytes = 0;
+        const hipError_t err = hipMalloc(&e.dev, dev_need);
+        if (err != hipSuccess) return fail(MPC_ERR_ALLOC, "entropy stage buffers of %zu bytes: %s", dev_need, hipGetErrorString(err));
+        e.dev_bytes = dev_need;
+        // the dense code tables are zero between frames (phase 2 clears what it set)
+        HIP_TRY(hipMemset(e.dev, 0, dev_need));
+    }
+    if (host_need > e.host_bytes) {
+        if (e.host) (void)hipHostFree(e.host);
+        e.host = nullptr;
+        e.host_bytes = 0;
+        const hipError_t err = hipHostMalloc(&e.host, host_need, hipHostMallocDefault);
+        if (err != hipSuccess) return fail(MPC_ERR_ALLOC, "pinned entropy stage buffers of %zu bytes: %s", host_need, hipGetErrorString(err));
+        e.host_bytes = host_need;
+    }
+    if (c->ent_hist_streams < S) {
+        HIP_TRY(hipDeviceSynchronize());
+        if (c->ent_hist) (void)hipFree(c->ent_hist);
+        c->ent_hist = nullptr;
+        c->ent_hist_streams = 0;
+        const size_t words = static_cast<size_t>(65536) * S;
+        const hipError_t err = hipMalloc(reinterpret_cast<void**>(&c->ent_hist), 2 * words * sizeof(unsigned));
+        if (err != hipSuccess) return fail(MPC_ERR_ALLOC, "histogram tables: %s", hipGetErrorString(err));
+        HIP_TRY(hipMemset(c->ent_hist, 0, words * sizeof(unsigned)));
+        HIP_TRY(hipMemset(c->ent_hist + words, 0xFF, words * sizeof(unsigned)));
+        c->ent_hist_streams = S;
+    }
+    char* d = static_cast<char*>(e.dev);
+    char* h = static_cast<char*>(e.host);
+    mpc::EntropyArgs& a = b->args;
+    a = mpc::EntropyArgs{};
+    a.n_lengths = static_cast<unsigned>(n_tc);
+    a.n_streams = S;
+    a.streams = reinterpret_cast<mpc::EntStream*>(d); d += streams_b;
+    a.totals = reinterpret_cast<unsigned*>(d); d += totals_b;
+    a.blk_lead = reinterpret_cast<unsigned*>(d); d += blk_u32;
+    a.blk_inner = reinterpret_cast<unsigned*>(d); d += blk_u32;
+    a.blk_tail = reinterpret_cast<unsigned*>(d); d += blk_u32;
+    a.blk_carry = reinterpret_cast<unsigned*>(d); d += blk_u32;
+    a.blk_out = reinterpret_cast<unsigned*>(d); d += blk_u32;
+    a.blk_bits = reinterpret_cast<unsigned*>(d); d += blk_u32;
+    a.blk_bit_off = reinterpret_cast<unsigned long long*>(d); d += blk_u64;
+    a.triples = reinterpret_cast<unsigned*>(d); d += triples_b;
+    b->d_entries = reinterpret_cast<unsigned*>(d); d += triples_b;
+    a.packed = reinterpret_cast<uint16_t*>(d); d += packed_b;
+    a.tcode = reinterpret_cast<unsigned*>(d); d += tcode_b;
+    a.tlen = reinterpret_cast<uint8_t*>(d); d += tlen_b;
+    b->d_out = reinterpret_cast<uint8_t*>(d); d += out_b;
+    a.triple_cap = kTripleCap;
+    a.ghist = c->ent_hist;
+    a.gfirst = c->ent_hist + static_cast<size_t>(65536) * c->ent_hist_streams;
+    a.entries = b->d_entries;
+    a.out32 = reinterpret_cast<unsigned*>(b->d_out);
+    b->out_capacity = out_b;
+    b->capacity_symbols = cap_symbols;
+    b->h_streams = reinterpret_cast<mpc::EntStream*>(h); h += streams_b;
+    b->h_totals = reinterpret_cast<unsigned*>(h); h += totals_b;
+    b->h_triples = reinterpret_cast<unsigned*>(h); h += triples_b;
+    b->h_entries = reinterpret_cast<unsigned*>(h); h += triples_b;
+    b->h_out = reinterpret_cast<uint8_t*>(h); h += out_b;
+    return MPC_OK;
+}
+
+enum class EntropyResult { kDone, kNeedsHost, kFailed };
+
+// The host's part and phase 2, on `s` (phase 1 has completed).  kNeedsHost: nothing written, take the host route.
+EntropyResult finish_entropy_on_device(const EntropyBuffers& b, int device_block_size, int width, int height, int K, const double* quant,
+                                       hipStream_t s, uint8_t** blob, size_t* nbytes) {
+    const mpc::EntropyArgs& a = b.args;
+    const int S = a.n_streams;
+    if (hipMemcpyAsync(b.h_streams, a.streams, sizeof(mpc::EntStream) * S, hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipMemcpyAsync(b.h_totals, a.totals, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess)
+        return EntropyResult::kFailed;
+    if (b.h_totals[3] != 0 || b.h_totals[2] > kTripleCap) return EntropyResult::kNeedsHost;
+    const unsigned n_triples = b.h_totals[2];
+    if (n_triples && (hipMemcpyAsync(b.h_triples, a.triples, sizeof(unsigned) * 3 * n_triples, hipMemcpyDeviceToHost, s) != hipSuccess ||
+                      hipStreamSynchronize(s) != hipSuccess))
+        return EntropyResult::kFailed;
+    std::vector<mpc::StreamPlan> plans(static_cast<size_t>(S));
+    mpc::parallel_jobs(S, [&](int j) {
+        const mpc::EntStream& st = b.h_streams[j];
+        mpc::plan_stream(j != 0, st.shorter != 0, st.rle_size, st.eff_n, st.largest, b.h_triples + 3 * static_cast<size_t>(st.triple_off),
+                         st.distinct, plans[static_cast<size_t>(j)]);
+    });
+    const mpc::BitWriter head = mpc::container_head(width, height, K, device_block_size, quant);
+    unsigned long long bit = head.bit_size(), raw_symbols = 0;
+    size_t n_entries = 0;
+    for (int j = 0; j < S; ++j) {
+        const mpc::StreamPlan& p = plans[static_cast<size_t>(j)];
+        if (p.mode == 0 && p.max_code_length > 32) return EntropyResult::kNeedsHost;
+        mpc::EntStream& st = b.h_streams[j];
+        bit += p.pre.bit_size();
+        st.bit_off = bit;
+        st.mode = static_cast<unsigned>(p.mode);
+        st.m = p.m;
+        bit += p.payload_bits + p.post.bit_size();
+        raw_symbols += st.n;
+        n_entries += p.entries.size() / 3;
+    }
+    const size_t total_bytes = static_cast<size_t>((bit + 7) / 8), out_words = (total_bytes + 3) / 4;
+    if (out_words * 4 > b.out_capacity || n_entries > kTripleCap) return EntropyResult::kNeedsHost;
+    size_t at = 0;
+    for (int j = 0; j < S; ++j) {
+        const std::vector<uint32_t>& e = plans[static_cast<size_t>(j)].entries;
+        for (size_t k = 0; k < e.size(); k += 3) {
+            b.h_entries[at++] = (static_cast<unsigned>(j) << 16) | e[k];
+            b.h_entries[at++] = e[k + 1];
+            b.h_entries[at++] = e[k + 2];
+        }
+    }
+    mpc::EntropyArgs a2 = a;
+    a2.n_entries = static_cast<unsigned>(n_entries);
+    a2.out_words = out_words;
+    if (hipMemcpyAsync(a.streams, b.h_streams, sizeof(mpc::EntStream) * S, hipMemcpyHostToDevice, s) != hipSuccess ||
+        (n_entries && hipMemcpyAsync(b.d_entries, b.h_entries, sizeof(unsigned) * 3 * n_entries, hipMemcpyHostToDevice, s) != hipSuccess) ||
+        hipMemsetAsync(b.d_out, 0, out_words * 4, s) != hipSuccess ||
+        mpc::launch_entropy_phase2(a2, raw_symbols, s) != 0 ||
+        hipMemcpyAsync(b.h_out, b.d_out, out_words * 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipMemcpyAsync(b.h_streams, a.streams, sizeof(mpc::EntStream) * S, hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess)
+        return EntropyResult::kFailed;
+    for (int j = 0; j < S; ++j)                                 // the device wrote exactly the bits the tables promise
+        if (b.h_streams[j].coded_bits != plans[static_cast<size_t>(j)].payload_bits) return EntropyResult::kFailed;
+    mpc::or_bits(b.h_out, 0, head);
+    for (int j = 0; j < S; ++j) {
+        const mpc::StreamPlan& p = plans[static_cast<size_t>(j)];
+        const unsigned long long payload = b.h_streams[j].bit_off;
+        mpc::or_bits(b.h_out, static_cast<size_t>(payload - p.pre.bit_size()), p.pre);
+        mpc::or_bits(b.h_out, static_cast<size_t>(payload + p.payload_bits), p.post);
+    }
+    uint8_t* out = static_cast<uint8_t*>(std::malloc(total_bytes ? total_bytes : 1));
+    if (!out) return EntropyResult::kFailed;
+    std::memcpy(out, b.h_out, total_bytes);
+    *blob = out;
+    *nbytes = total_bytes;
+    return EntropyResult::kDone;
+}
+}  // namespace
+
 // compressed::encodeImage for a sequence of equally sized frames: device tile encode, device stream assembly (only the live
 // symbols cross PCIe, stream by stream), host entropy stage -- pipelined over kSeqSlots slots.  Frames come from host memory
 // (uploaded through the slot's pinned image on an upload stream) or are already resident on the device.
@@ -1158,6 +1376,13 @@ static mpc_status encode_sequence(mpc_context* c, const uint8_t* const* frames, 
     }
     HIP_TRY(ensure_workspace(c, static_cast<long long>(n_tc)) == MPC_OK ? hipSuccess : hipErrorOutOfMemory);
     const double* q = quant ? quant : c->quant.data();
+    const bool device_entropy = !host_entropy_forced();
+    EntropyBuffers ent[S];
+    if (device_entropy)
+        for (size_t sl = 0; sl < slots; ++sl) {
+            const mpc_status es = entropy_buffers(c, static_cast<int>(sl), tiles, K, &ent[sl]);
+            if (es != MPC_OK) return es;
+        }
     struct Pending {
         std::future<std::pair<uint8_t*, size_t>> result;     // malloc'ed container, or {nullptr, 0}
         int frame = -1;
@@ -1230,6 +1455,13 @@ static mpc_status encode_sequence(mpc_context* c, const uint8_t* const* frames, 
                                      nullptr, nullptr, 0, c->seq_compute);
         if (st != MPC_OK) break;
         MPC_SEQ_TRY(static_cast<hipError_t>(mpc::launch_stream_assembly(sa, c->seq_compute)));
+        EntropyBuffers eb = ent[sl];
+        if (device_entropy) {
+            eb.args.counts = d_counts;
+            eb.args.symbols = sa.symbols;
+            eb.args.stream_off = sa.stream_off;
+            MPC_SEQ_TRY(static_cast<hipError_t>(mpc::launch_entropy_phase1(eb.args, eb.capacity_symbols, c->seq_compute)));
+        }
         hipEvent_t ev_comp = c->seq_events[sl][1];
         MPC_SEQ_TRY(hipEventRecord(ev_comp, c->seq_compute));
         const int bs = c->block_size, device = c->device;
@@ -1251,6 +1483,14 @@ static mpc_status encode_sequence(mpc_context* c, const uint8_t* const* frames, 
             } tr{trace, f, t_enq};
             if (hipSetDevice(device) != hipSuccess || hipEventSynchronize(ev_comp) != hipSuccess) return {nullptr, 0};
             tr.t1 = now_ms();
+            if (device_entropy) {
+                uint8_t* blob = nullptr;
+                size_t n = 0;
+                const EntropyResult r = finish_entropy_on_device(eb, bs, width, height, K, q, down, &blob, &n);
+                tr.t2 = tr.t3 = now_ms();
+                if (r == EntropyResult::kDone) return {blob, n};
+                if (r == EntropyResult::kFailed) return {nullptr, 0};
+            }
             if (hipMemcpyAsync(off, d_off, sizeof(unsigned long long) * n_off, hipMemcpyDeviceToHost, down) != hipSuccess) return {nullptr, 0};
             if (hipMemcpyAsync(counts, d_counts, sizeof(uint16_t) * n_tc, hipMemcpyDeviceToHost, down) != hipSuccess) return {nullptr, 0};
             if (hipEventRecord(ev_down, down) != hipSuccess || hipEventSynchronize(ev_down) != hipSuccess) return {nullptr, 0};
@@ -1328,6 +1568,19 @@ mpc_status mpc_records_to_container_device(mpc_context* c, const uint16_t* d_cou
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int err = mpc::launch_stream_assembly(sa, s);
     if (err != 0) return fail(MPC_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(err)));
+    if (!host_entropy_forced()) {
+        EntropyBuffers eb;
+        const mpc_status es = entropy_buffers(c, 0, tiles, K, &eb);
+        if (es != MPC_OK) return es;
+        eb.args.counts = d_counts;
+        eb.args.symbols = sa.symbols;
+        eb.args.stream_off = sa.stream_off;
+        const int e1 = mpc::launch_entropy_phase1(eb.args, eb.capacity_symbols, s);
+        if (e1 != 0) return fail(MPC_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(e1)));
+        const EntropyResult r = finish_entropy_on_device(eb, c->block_size, width, height, K, quant ? quant : c->quant.data(), s, bytes, nbytes);
+        if (r == EntropyResult::kDone) return MPC_OK;
+        if (r == EntropyResult::kFailed) return fail(MPC_ERR_HIP, "device entropy stage failed: %s", hipGetErrorString(hipGetLastError()));
+    }
     const size_t n_off = 6 * static_cast<size_t>(K) + 1;
     HIP_TRY(hipMemcpyAsync(off, sa.stream_off, sizeof(unsigned long long) * n_off, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(counts, d_counts, sizeof(uint16_t) * n_tc, hipMemcpyDeviceToHost, s));
@@ -1337,6 +1590,58 @@ mpc_status mpc_records_to_container_device(mpc_context* c, const uint16_t* d_cou
     if (total) HIP_TRY(hipMemcpyAsync(symbols, sa.symbols, sizeof(uint16_t) * total, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     *bytes = mpc::encode_symbol_streams_malloc(width, height, K, c->block_size, quant ? quant : c->quant.data(), counts, symbols, off, nbytes);
+    return *bytes ? MPC_OK : fail(MPC_ERR_ALLOC, "out of memory");
+    });
+}
+
+// The entropy stage alone, on streams the caller holds in host memory (what mpc_assemble_symbol_streams codes on the host):
+// upload, device entropy stage, container bytes.  *route (optional): 0 = coded on the device, 1 = the host route was taken.
+mpc_status mpc_code_symbol_streams_device(mpc_context* c, int width, int height, const double* quant, const uint16_t* counts,
+                                          const uint16_t* symbols, const unsigned long long* stream_off, uint8_t** bytes, size_t* nbytes,
+                                          int* route) {
+    return guarded([&]() -> mpc_status {
+    if (!c || !counts || !stream_off || !bytes || !nbytes || width < 1 || height < 1) return fail(MPC_ERR_ARGUMENT, "bad argument");
+    if (c->device < 0) return fail(MPC_ERR_NO_DEVICE, "context was created without a device");
+    const int K = c->K;
+    const size_t tiles = static_cast<size_t>((width + 7) / 8) * ((height + 7) / 8), n_tc = tiles * 3;
+    for (int s = 0; s < 6 * K; ++s)
+        if (stream_off[s + 1] < stream_off[s]) return fail(MPC_ERR_ARGUMENT, "stream offsets must not decrease");
+    const unsigned long long total = stream_off[6 * K];
+    if (stream_off[0] != 0 || total > 2ULL * n_tc * K || (total && !symbols)) return fail(MPC_ERR_ARGUMENT, "streams larger than a frame of this size can hold");
+    const double* q = quant ? quant : c->quant.data();
+    std::lock_guard<std::recursive_mutex> one_host_call(c->host_calls);
+    HIP_TRY(hipSetDevice(c->device));
+    if (route) *route = 1;
+    if (!host_entropy_forced()) {
+        EntropyBuffers eb;
+        const mpc_status es = entropy_buffers(c, 0, tiles, K, &eb);
+        if (es != MPC_OK) return es;
+        struct Temp {
+            void* p = nullptr;
+            ~Temp() { if (p) (void)hipFree(p); }
+        } d_counts, d_symbols, d_off;
+        const size_t n_off = 6 * static_cast<size_t>(K) + 1;
+        HIP_TRY(hipMalloc(&d_counts.p, sizeof(uint16_t) * n_tc));
+        HIP_TRY(hipMalloc(&d_symbols.p, sizeof(uint16_t) * (total ? total : 1)));
+        HIP_TRY(hipMalloc(&d_off.p, sizeof(unsigned long long) * n_off));
+        HIP_TRY(hipMemcpy(d_counts.p, counts, sizeof(uint16_t) * n_tc, hipMemcpyHostToDevice));
+        if (total) HIP_TRY(hipMemcpy(d_symbols.p, symbols, sizeof(uint16_t) * total, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_off.p, stream_off, sizeof(unsigned long long) * n_off, hipMemcpyHostToDevice));
+        eb.args.counts = static_cast<const uint16_t*>(d_counts.p);
+        eb.args.symbols = static_cast<const uint16_t*>(d_symbols.p);
+        eb.args.stream_off = static_cast<const unsigned long long*>(d_off.p);
+        const int e1 = mpc::launch_entropy_phase1(eb.args, eb.capacity_symbols, nullptr);
+        if (e1 != 0) return fail(MPC_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(e1)));
+        HIP_TRY(hipStreamSynchronize(nullptr));
+        const EntropyResult r = finish_entropy_on_device(eb, c->block_size, width, height, K, q, nullptr, bytes, nbytes);
+        HIP_TRY(hipDeviceSynchronize());
+        if (r == EntropyResult::kDone) {
+            if (route) *route = 0;
+            return MPC_OK;
+        }
+        if (r == EntropyResult::kFailed) return fail(MPC_ERR_HIP, "device entropy stage failed: %s", hipGetErrorString(hipGetLastError()));
+    }
+    *bytes = mpc::encode_symbol_streams_malloc(width, height, K, c->block_size, q, counts, symbols, stream_off, nbytes);
     return *bytes ? MPC_OK : fail(MPC_ERR_ALLOC, "out of memory");
     });
 }

@@ -181,6 +181,22 @@ mpc_status mpc_assemble_planar_streams(int width, int height, int K, int block_s
 mpc_status mpc_assemble_symbol_streams(int width, int height, int K, int block_size, const double* quant, const uint16_t* counts,
                                        const uint16_t* symbols, const unsigned long long* stream_off, uint8_t** bytes, size_t* nbytes);
 
+/* The same container by the route the device-side entropy stage takes (per-stream statistics -> Huffman table or Golomb M
+ * and bit offsets -> codes written at their offsets), with the device's share computed on the host: a host-only check of
+ * the planning half against mpc_assemble_symbol_streams. */
+mpc_status mpc_assemble_symbol_streams_by_plan(int width, int height, int K, int block_size, const double* quant, const uint16_t* counts,
+                                               const uint16_t* symbols, const unsigned long long* stream_off, uint8_t** bytes, size_t* nbytes);
+
+/* The entropy stage of writeCompressed (CompressedImage.cpp:403-460: run-length decision, Huffman-or-Golomb choice, coding)
+ * for streams the caller holds in host memory, with the per-symbol work on the device (mp_entropy.hip): run lengths,
+ * histograms and first appearances are taken on the device, the host builds one code table per stream, the device writes
+ * the codes.  Inputs as for mpc_assemble_symbol_streams (counts[3 * tiles] is the `lengths` stream; K and block size are the
+ * context's; quant NULL = the context's tables); same bytes.  *route (optional): 0 = coded on the device, 1 = a stream was
+ * outside what the device tables hold (or MPC_HOST_ENTROPY=1) and the host coded the container. */
+mpc_status mpc_code_symbol_streams_device(mpc_context* ctx, int width, int height, const double* quant, const uint16_t* counts,
+                                          const uint16_t* symbols, const unsigned long long* stream_off, uint8_t** bytes, size_t* nbytes,
+                                          int* route);
+
 /* readCompressed (CompressedImage.cpp:635): parse a container; streams come back with the DC differencing
  * undone.  index -1 = lengths, 0..6K-1 = codes[index]. */
 mpc_status mpc_read_compressed(const uint8_t* bytes, size_t nbytes, mpc_streams** out);

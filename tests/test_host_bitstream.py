@@ -241,3 +241,17 @@ def test_truncated_and_corrupted_containers_are_errors_not_crashes(ia, oracle, m
         ia.read_compressed(bytes(huge))
     with pytest.raises(ia.MpcError):
         ia.read_compressed(mn_bytes[: len(mn_bytes) // 2])
+
+
+def test_symbol_streams_direct_and_planned_routes_equal_the_oracle(ia, oracle):
+    """The container from assembled streams, on adversarial streams (tests/stream_cases.py): the host's direct route, and the
+    route the device-side entropy stage takes (statistics -> plan_stream -> codes at planned offsets -> or_bits) with the
+    device's share done on the host, both against the oracle's writeCompressed."""
+    import stream_cases
+    c = stream_cases.make()
+    q = stream_cases.quant(c["K"])
+    want = oracle.write_compressed(dict(W=c["W"], H=c["H"], K=c["K"], bs=c["bs"], quant=q, lengths=c["counts"], codes=c["as_held"]))
+    direct = ia.assemble_symbol_streams(c["W"], c["H"], c["K"], c["bs"], q, c["counts"], c["as_coded"])
+    assert direct == want
+    planned = ia.assemble_symbol_streams(c["W"], c["H"], c["K"], c["bs"], q, c["counts"], c["as_coded"], by_plan=True)
+    assert planned == want
