@@ -195,7 +195,7 @@ def main():
         ptr = d_rgb.data_ptr()
 
         def run(n):                                          # n steps = n frames through the pipeline, in one call
-            return ctx.encode_images_device([ptr] * n, W, H)
+            return ctx.encode_images_device([ptr] * n, W, H, views=True)     # the library's buffers as they are (no Python copy)
     else:
         striped = sharding.StripedEncoder(ctx, W, H, frames, world, rank, args.backend)
 

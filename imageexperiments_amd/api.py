@@ -129,6 +129,31 @@ def _take_bytes(L, p, n):
     return out
 
 
+class _Owned:
+    """Keeps a buffer the library malloc'ed alive for the numpy view built on it, and frees it with mpc_free."""
+
+    def __init__(self, L, p):
+        self.L, self.p = L, C.cast(p, C.c_void_p)
+
+    def __del__(self):
+        if self.p:
+            self.L.mpc_free(self.p)
+            self.p = None
+
+
+def _take_view(L, p, n):
+    """The container as a read-only uint8 array ON the library's buffer (no copy; the array owns the buffer)."""
+    if not n.value:
+        L.mpc_free(C.cast(p, C.c_void_p))
+        return np.zeros(0, np.uint8)
+    owner = _Owned(L, p)
+    buf = (C.c_uint8 * n.value).from_address(C.cast(p, C.c_void_p).value)
+    buf._owner = owner                                   # the ctypes array is the base of the view: freed with it
+    out = np.frombuffer(buf, np.uint8)
+    out.flags.writeable = False
+    return out
+
+
 def _take_u16(L, p, n):
     out = np.ctypeslib.as_array(p, shape=(n.value,)).copy() if n.value else np.zeros(0, np.uint16)
     L.mpc_free(C.cast(p, C.c_void_p))
@@ -486,9 +511,10 @@ class CompressionContext:
         _check(self.L.mpc_encode_images(self.h, ptrs, n, W, H, qp, outs, sizes))
         return [_take_bytes(self.L, outs[i], C.c_size_t(sizes[i])) for i in range(n)]
 
-    def encode_images_device(self, d_frames, width, height, quant=None):
+    def encode_images_device(self, d_frames, width, height, quant=None, views=False):
         """mpc_encode_images_device: frames already in device memory (ints from tensor.data_ptr(), tightly packed RGB).
-        Returns a list of bytes objects (containers), pipelined like encode_images."""
+        Returns a list of bytes objects (containers), pipelined like encode_images; views=True: read-only uint8 arrays on the
+        buffers the library returned instead (what a C caller holds: no Python-side copy of every container)."""
         qp = None
         if quant is not None:
             quant = np.ascontiguousarray(quant, np.float64).reshape(3, self.K)
@@ -498,7 +524,8 @@ class CompressionContext:
         outs = (_u8p * n)()
         sizes = (C.c_size_t * n)()
         _check(self.L.mpc_encode_images_device(self.h, ptrs, n, width, height, qp, outs, sizes))
-        return [_take_bytes(self.L, outs[i], C.c_size_t(sizes[i])) for i in range(n)]
+        take = _take_view if views else _take_bytes
+        return [take(self.L, outs[i], C.c_size_t(sizes[i])) for i in range(n)]
 
     def encode_image_device(self, d_rgb, width, height, quant=None):
         return self.encode_images_device([d_rgb], width, height, quant)[0]

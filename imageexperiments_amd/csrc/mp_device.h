@@ -232,11 +232,13 @@ struct EntropyArgs {
     unsigned long long* blk_bit_off;    // ... bit offset of its first code in the container
     unsigned* ghist;                    // [n_streams][65536] zero between calls
     unsigned* gfirst;                   // [n_streams][65536] 0xFFFFFFFF between calls
-    unsigned* triples;                  // [triple_cap][3]
+    unsigned* triples;                  // [triple_cap][3], in (mapped) host memory: the compaction writes it across PCIe
     unsigned triple_cap;
+    EntStream* host_streams;            // [n_streams] mirror of `streams` in (mapped) host memory
+    unsigned* host_totals;              // [4] mirror of `totals`
     unsigned* tcode;                    // [n_streams][65536] zero between calls
     uint8_t* tlen;                      // [n_streams][65536]
-    const unsigned* entries;            // [n_entries][3]: stream << 16 | symbol, code, length
+    const unsigned* entries;            // [n_entries][3]: stream << 16 | symbol, code, length (may be mapped host memory)
     unsigned n_entries;
     unsigned* out32;                    // the container, zeroed
     unsigned long long out_words;

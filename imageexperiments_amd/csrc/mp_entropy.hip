@@ -15,7 +15,9 @@
 //              closed form, output offsets, the reference's decision `packed.size() + 4 < stream.size()`
 //     pack     the run-length coded stream, for the streams where it is shorter
 //     hist     histogram and first position of every symbol of the stream that will be coded (LDS for symbols < 8192)
-//     compact  (symbol, count, first position) of the symbols that occur, per stream, in one list for the host
+//     hist     ... and the number of distinct symbols (a bin's first count)
+//     compact  (symbol, count, first position) of the symbols that occur, per stream, in one list written straight to host memory
+//     mirror   the per-stream records to host memory
 //   host: Huffman tables / Golomb parameter, bit offsets of every stream's payload in the container
 //   phase 2
 //     tables   scatter the (symbol -> code, length) entries into dense per-stream tables
@@ -151,18 +153,25 @@ __global__ __launch_bounds__(kThreads) void ent_runs_kernel(const EntropyArgs a)
     if (b >= a.totals[0]) return;
     const int j = find_stream<false>(a, b);
     const EntStream s = a.streams[j];
+    const unsigned lb = b - s.blk_begin;
+    const unsigned begin = lb * kEntBlock, len = min((unsigned)kEntBlock, s.n - begin);
+    const uint16_t* src = raw_stream(a, j, s);
     if (j == 0) {                                         // `lengths` is never run-length coded (CompressedImage.cpp:424)
-        if (!kPack && threadIdx.x == 0) {
-            a.blk_lead[b] = 0;
-            a.blk_inner[b] = 0;
-            a.blk_tail[b] = 0;
+        if (!kPack) {
+            unsigned largest = 0;
+            for (unsigned i = threadIdx.x; i < len; i += kThreads) largest = max(largest, (unsigned)src[begin + i]);
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) largest = max(largest, (unsigned)__shfl_xor((int)largest, d));
+            if ((threadIdx.x & 63) == 0) atomicMax(&a.streams[0].largest, largest);
+            if (threadIdx.x == 0) {
+                a.blk_lead[b] = 0;
+                a.blk_inner[b] = 0;
+                a.blk_tail[b] = 0;
+            }
         }
         return;
     }
     if (kPack && !s.shorter) return;
-    const unsigned lb = b - s.blk_begin;
-    const unsigned begin = lb * kEntBlock, len = min((unsigned)kEntBlock, s.n - begin);
-    const uint16_t* src = raw_stream(a, j, s);
     if (threadIdx.x == 0) {
         first_bnd = (int)len;
         last_bnd = -1;
@@ -178,12 +187,14 @@ __global__ __launch_bounds__(kThreads) void ent_runs_kernel(const EntropyArgs a)
     }
     unsigned bnd_mask = 0, end_mask = 0;                  // bit k: position t0 + k starts / ends a maximal run
     int my_last = -1;
+    unsigned largest = 0;                                 // of the symbols that will be coded (kPack: of the run lengths)
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
         const unsigned i = t0 + k, gi = begin + i;
         if (i < len) {
             if (gi == 0 || v[k + 1] != v[k]) { bnd_mask |= 1u << k; my_last = (int)i; }
             if (gi == s.n - 1 || v[k + 2] != v[k + 1]) end_mask |= 1u << k;
+            if (!kPack) largest = max(largest, (unsigned)v[k + 1]);
         }
     }
     __syncthreads();
@@ -228,6 +239,9 @@ __global__ __launch_bounds__(kThreads) void ent_runs_kernel(const EntropyArgs a)
         }
     }
     if (!kPack) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) largest = max(largest, (unsigned)__shfl_xor((int)largest, d));
+        if ((threadIdx.x & 63) == 0) atomicMax(&a.streams[j].largest, largest);
         const unsigned w = wave_incl_add(emitted);
         if ((threadIdx.x & 63) == 63 && w) atomicAdd(&inner_sum, w);
         __syncthreads();
@@ -257,10 +271,16 @@ __global__ __launch_bounds__(kThreads) void ent_runs_kernel(const EntropyArgs a)
                 const unsigned p = cur >= 0 ? i - (unsigned)cur : carry + i;
                 const unsigned c = p % kChunk;
                 if (c <= 1) dst[at++] = v[k + 1];
-                if (c >= 1 && (((end_mask >> k) & 1u) || c == kChunk - 1)) dst[at++] = (uint16_t)(c - 1);
+                if (c >= 1 && (((end_mask >> k) & 1u) || c == kChunk - 1)) {
+                    dst[at++] = (uint16_t)(c - 1);
+                    largest = max(largest, c - 1);
+                }
             }
         }
     }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) largest = max(largest, (unsigned)__shfl_xor((int)largest, d));
+    if ((threadIdx.x & 63) == 0 && largest > s.largest) atomicMax(&a.streams[j].largest, largest);
 }
 
 // one wave per stream
@@ -323,70 +343,83 @@ __global__ __launch_bounds__(kThreads) void ent_hist_kernel(const EntropyArgs a)
     if (begin >= s.eff_n) return;
     const unsigned end = min(s.eff_n, begin + kEntHistSpan * kEntBlock);
     const uint16_t* src = s.shorter ? a.packed + s.raw_off : raw_stream(a, j, s);
-    for (int i = threadIdx.x; i < kLdsBins; i += kThreads) {
+    const int bins = (int)min((unsigned)kLdsBins, s.largest + 1);       // the runs kernels have found the largest symbol
+    for (int i = threadIdx.x; i < bins; i += kThreads) {
         hist[i] = 0;
         first[i] = kNoPos;
     }
     __syncthreads();
     unsigned* ghist = a.ghist + (size_t)j * 65536;
     unsigned* gfirst = a.gfirst + (size_t)j * 65536;
-    unsigned largest = 0;
+    unsigned fresh = 0;                                   // bins this thread was the first to count into
     for (unsigned i = begin + threadIdx.x; i < end; i += kThreads) {
         const unsigned sym = src[i];
-        largest = max(largest, sym);
         if (sym < kLdsBins) {
             atomicAdd(&hist[sym], 1u);
             atomicMin(&first[sym], i);
         } else {
-            atomicAdd(&ghist[sym], 1u);
+            fresh += atomicAdd(&ghist[sym], 1u) == 0;
             atomicMin(&gfirst[sym], i);
         }
     }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) largest = max(largest, (unsigned)__shfl_xor((int)largest, d));
-    if ((threadIdx.x & 63) == 0) atomicMax(&a.streams[j].largest, largest);
     __syncthreads();
-    for (int i = threadIdx.x; i < kLdsBins; i += kThreads) {
+    for (int i = threadIdx.x; i < bins; i += kThreads) {
         const unsigned h = hist[i];
         if (h) {
-            atomicAdd(&ghist[i], h);
+            fresh += atomicAdd(&ghist[i], h) == 0;
             atomicMin(&gfirst[i], first[i]);
         }
     }
+    fresh = wave_incl_add(fresh);
+    if ((threadIdx.x & 63) == 63 && fresh) atomicAdd(&a.streams[j].distinct, fresh);
 }
 
-// one workgroup per stream: the bins that occur -> (symbol, count, first position), ascending symbols; bins reset
-__global__ __launch_bounds__(kThreads) void ent_compact_kernel(const EntropyArgs a)
+// where each stream's triples go in the list: exclusive scan of the distinct counts
+__global__ __launch_bounds__(kThreads) void ent_triple_offsets_kernel(const EntropyArgs a)
 {
-    __shared__ unsigned scratch[kThreads / 64];
-    __shared__ unsigned base_at;
-    const int j = blockIdx.x;
-    const EntStream s = a.streams[j];
-    unsigned* ghist = a.ghist + (size_t)j * 65536;
-    unsigned* gfirst = a.gfirst + (size_t)j * 65536;
-    const unsigned bins = s.eff_n ? s.largest + 1 : 0;
-    unsigned mine = 0;
-    for (unsigned i = threadIdx.x; i < bins; i += kThreads) mine += ghist[i] != 0;
-    unsigned distinct;
-    block_excl_add(mine, scratch, &distinct);
-    if (threadIdx.x == 0) {
-        const unsigned at = atomicAdd(&a.totals[2], distinct);
-        base_at = at;
-        a.streams[j].distinct = distinct;
-        a.streams[j].triple_off = at;
-        if (at + distinct > a.triple_cap) a.totals[3] = 1;
+    __shared__ unsigned distinct[kEntMaxStreams];
+    const int j = threadIdx.x;
+    if (j < a.n_streams) {
+        distinct[j] = a.streams[j].distinct;
+        a.streams[j].reserved = 0;                        // the stream's write cursor
     }
     __syncthreads();
-    const bool room = base_at + distinct <= a.triple_cap;
-    unsigned run = base_at;
-    for (unsigned i0 = 0; i0 < bins; i0 += kThreads) {
-        const unsigned i = i0 + threadIdx.x;
-        const unsigned h = i < bins ? ghist[i] : 0u;
-        unsigned total;
-        const unsigned rank = block_excl_add(h != 0, scratch, &total);
+    if (threadIdx.x == 0) {
+        unsigned at = 0;
+        for (int s = 0; s < a.n_streams; ++s) {
+            a.streams[s].triple_off = at;
+            at += distinct[s];
+        }
+        a.totals[2] = at;
+        a.totals[3] = at > a.triple_cap;
+    }
+}
+
+// grid (1024-bin chunk, stream): the bins that occur -> (symbol, count, first position) in the stream's part of the list (any
+// order: the host sorts them by first position anyway); bins reset for the next frame
+__global__ __launch_bounds__(kThreads) void ent_compact_kernel(const EntropyArgs a)
+{
+    const int j = blockIdx.y;
+    const EntStream s = a.streams[j];
+    const unsigned chunk = blockIdx.x * 4 * kThreads;
+    if (s.eff_n == 0 || chunk > s.largest) return;
+    unsigned* ghist = a.ghist + (size_t)j * 65536;
+    unsigned* gfirst = a.gfirst + (size_t)j * 65536;
+    const bool room = a.totals[3] == 0;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long below = (1ULL << lane) - 1ULL;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const unsigned i = chunk + k * kThreads + threadIdx.x;
+        const unsigned h = i <= s.largest ? ghist[i] : 0u;
+        const unsigned long long hit = __ballot(h != 0);
+        if (!hit) continue;
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(&a.streams[j].reserved, (unsigned)__popcll(hit));
+        base = __shfl(base, 0);
         if (h) {
             if (room) {
-                unsigned* t = a.triples + 3 * (size_t)(run + rank);
+                unsigned* t = a.triples + 3 * (size_t)(s.triple_off + base + (unsigned)__popcll(hit & below));
                 t[0] = i;
                 t[1] = h;
                 t[2] = gfirst[i];
@@ -394,8 +427,19 @@ __global__ __launch_bounds__(kThreads) void ent_compact_kernel(const EntropyArgs
             ghist[i] = 0;
             gfirst[i] = kNoPos;
         }
-        run += total;
     }
+}
+
+// The per-stream records and the totals, to their mirrors in host memory (and back, with the host's part filled in): kernels
+// write them across PCIe themselves -- a copy command would be a blit kernel or an SDMA packet queued somewhere else, and this
+// way the host needs nothing but the event behind the kernel.
+__global__ __launch_bounds__(kThreads) void ent_mirror_kernel(const EntropyArgs a, int to_host)
+{
+    const int words = (int)(sizeof(EntStream) / sizeof(unsigned)) * a.n_streams;
+    const unsigned* src = reinterpret_cast<const unsigned*>(to_host ? a.streams : a.host_streams);
+    unsigned* dst = reinterpret_cast<unsigned*>(to_host ? a.host_streams : a.streams);
+    for (int i = threadIdx.x; i < words; i += kThreads) dst[i] = src[i];
+    if (to_host && threadIdx.x < 4) a.host_totals[threadIdx.x] = a.totals[threadIdx.x];
 }
 
 // ---- phase 2 ----
@@ -540,7 +584,9 @@ int launch_entropy_phase1(const EntropyArgs& a, unsigned long long capacity_symb
     hipLaunchKernelGGL(ent_rle_plan_kernel, dim3((unsigned)a.n_streams), dim3(64), 0, st, a);
     hipLaunchKernelGGL(ent_runs_kernel<true>, dim3(blocks), dim3(kThreads), 0, st, a);
     hipLaunchKernelGGL(ent_hist_kernel, dim3(hblocks), dim3(kThreads), 0, st, a);
-    hipLaunchKernelGGL(ent_compact_kernel, dim3((unsigned)a.n_streams), dim3(kThreads), 0, st, a);
+    hipLaunchKernelGGL(ent_triple_offsets_kernel, dim3(1), dim3(kThreads), 0, st, a);
+    hipLaunchKernelGGL(ent_compact_kernel, dim3(65536 / (4 * kThreads), (unsigned)a.n_streams), dim3(kThreads), 0, st, a);
+    hipLaunchKernelGGL(ent_mirror_kernel, dim3(1), dim3(kThreads), 0, st, a, 1);
     return (int)hipGetLastError();
 }
 
@@ -550,11 +596,13 @@ int launch_entropy_phase2(const EntropyArgs& a, unsigned long long raw_symbols, 
     if (a.n_streams < 1 || a.n_streams > kEntMaxStreams) return (int)hipErrorInvalidValue;
     const unsigned blocks = (unsigned)entropy_max_blocks(raw_symbols, a.n_streams);
     const unsigned eblocks = (a.n_entries + kThreads - 1) / kThreads;
+    hipLaunchKernelGGL(ent_mirror_kernel, dim3(1), dim3(kThreads), 0, st, a, 0);
     if (eblocks) hipLaunchKernelGGL(ent_tables_kernel, dim3(eblocks), dim3(kThreads), 0, st, a, 0);
     hipLaunchKernelGGL(ent_code_kernel<false>, dim3(blocks), dim3(kThreads), 0, st, a);
     hipLaunchKernelGGL(ent_bit_offsets_kernel, dim3((unsigned)a.n_streams), dim3(64), 0, st, a);
     hipLaunchKernelGGL(ent_code_kernel<true>, dim3(blocks), dim3(kThreads), 0, st, a);
     if (eblocks) hipLaunchKernelGGL(ent_tables_kernel, dim3(eblocks), dim3(kThreads), 0, st, a, 1);
+    hipLaunchKernelGGL(ent_mirror_kernel, dim3(1), dim3(kThreads), 0, st, a, 1);
     return (int)hipGetLastError();
 }
 

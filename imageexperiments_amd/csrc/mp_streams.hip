@@ -7,8 +7,9 @@
 // live symbols stream by stream, in stream order, into ONE contiguous u16 buffer laid out in container order and apply the
 // DC differencing, so that only the live symbols cross PCIe and every host coding job starts from a finished stream:
 //   count    per block of 1024 tiles and channel: tiles with more than i atoms, for every i (from a histogram of the counts)
-//   scan     exclusive scan of those over the blocks (one thread per stream pair); stream sizes and offsets
-//   scatter  rank of every live symbol inside its block by ballots, write deltaId / intCoeff to their stream positions
+//   scan     exclusive scan of those over the blocks (one wave per stream pair); stream sizes
+//   scatter  stream offsets from the sizes; rank of every live symbol inside its block by ballots, write deltaId / intCoeff to
+//            their stream positions
 //   dc       zig-zag difference of the three step-0 coefficient streams (CompressedImage.cpp:428-446)
 // HBM-bound byte shuffling: reads are 16-byte vectors of whole records, writes are runs of consecutive u16.
 #include <hip/hip_runtime.h>
@@ -45,40 +46,51 @@ __global__ __launch_bounds__(kBlockTiles) void mp_stream_count_kernel(const Stre
     }
 }
 
-// one thread per (channel, step): exclusive scan over the blocks; thread 0 then lays the streams out in container order
-__global__ __launch_bounds__(128) void mp_stream_scan_kernel(const StreamArgs a, int blocks)
+// one wave per (channel, step): exclusive scan of the live counts over the blocks, in place; the stream's size
+__global__ __launch_bounds__(64) void mp_stream_scan_kernel(const StreamArgs a, int blocks)
 {
-    __shared__ unsigned total[3 * kMaxDeviceK];
-    if ((int)threadIdx.x < 3 * a.K) {
-        const int ch = threadIdx.x / a.K, i = threadIdx.x - ch * a.K;
-        unsigned run = 0;
-        for (int b = 0; b < blocks; ++b) {
-            const long long at = ((long long)b * 3 + ch) * a.K + i;
-            const unsigned n = a.block_live[at];
-            a.block_live[at] = run;                               // in place: live count -> offset of the block in its stream
-            run += n;
+    const int pair = blockIdx.x, ch = pair / a.K, i = pair - ch * a.K, lane = threadIdx.x;
+    unsigned run = 0;
+    for (int base = 0; base < blocks; base += 64) {
+        const int b = base + lane;
+        const long long at = ((long long)(b < blocks ? b : 0) * 3 + ch) * a.K + i;
+        const unsigned n = b < blocks ? a.block_live[at] : 0u;
+        unsigned incl = n;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
         }
-        total[threadIdx.x] = run;
-        a.sizes[threadIdx.x] = run;
+        if (b < blocks) a.block_live[at] = run + incl - n;            // live count -> offset of the block in its stream
+        run += __shfl(incl, 63);
+    }
+    if (lane == 0) a.sizes[pair] = run;
+}
+
+// the streams in container order: codes[2K*ch + 2i] = deltaId, [+1] = intCoeff, each sizes[ch*K + i] symbols
+__device__ __forceinline__ void stream_layout(const StreamArgs& a, unsigned long long* off /*[6K + 1], LDS*/)
+{
+    if (threadIdx.x == 0) {
+        unsigned long long at = 0;
+        for (int p = 0; p < 3 * a.K; ++p) {
+            const unsigned n = a.sizes[p];
+            off[2 * p] = at;
+            at += n;
+            off[2 * p + 1] = at;
+            at += n;
+        }
+        off[6 * a.K] = at;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long off = 0;
-        for (int ch = 0; ch < 3; ++ch)
-            for (int i = 0; i < a.K; ++i) {
-                const unsigned n = total[ch * a.K + i];
-                a.stream_off[2 * (ch * a.K + i)] = off;           // codes[2K*ch + 2i]     deltaId
-                off += n;
-                a.stream_off[2 * (ch * a.K + i) + 1] = off;       // codes[2K*ch + 2i + 1] intCoeff
-                off += n;
-            }
-        a.stream_off[6 * a.K] = off;                              // symbols in all
-    }
 }
 
 __global__ __launch_bounds__(kBlockTiles) void mp_stream_scatter_kernel(const StreamArgs a)
 {
     __shared__ unsigned wave_live[kWavesPerBlock][kMaxDeviceK];
+    __shared__ unsigned long long off[6 * kMaxDeviceK + 1];
+    stream_layout(a, off);
+    if (blockIdx.x == 0)                                          // for the kernels and copies that follow
+        for (int s = threadIdx.x; s <= 6 * a.K; s += kBlockTiles) a.stream_off[s] = off[s];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long t = (long long)blockIdx.x * kBlockTiles + threadIdx.x;
     const bool in = t < a.tiles;
@@ -118,7 +130,7 @@ __global__ __launch_bounds__(kBlockTiles) void mp_stream_scatter_kernel(const St
                 if (c > i) {
                     const unsigned long long pos = (unsigned long long)a.block_live[((long long)blockIdx.x * 3 + ch) * a.K + i] + before +
                                                    (unsigned)__popcll(live & below);
-                    const unsigned long long od = a.stream_off[2 * (ch * a.K + i)], oc = a.stream_off[2 * (ch * a.K + i) + 1];
+                    const unsigned long long od = off[2 * (ch * a.K + i)], oc = off[2 * (ch * a.K + i) + 1];
                     a.symbols[od + pos] = (uint16_t)(rec[i] & 0xFFFFu);
                     // step-0 coefficients go through the difference kernel: parked behind the end of all streams
                     uint16_t* coeff = i == 0 ? a.dc_tmp + (long long)ch * a.tiles : a.symbols + oc;
@@ -154,7 +166,7 @@ int launch_stream_assembly(const StreamArgs& a, void* stream_)
     const int blocks = (int)((a.tiles + kBlockTiles - 1) / kBlockTiles);
     if (blocks < 1 || a.K < 1 || a.K > kMaxDeviceK) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(mp_stream_count_kernel, dim3((unsigned)blocks), dim3(kBlockTiles), 0, s, a);
-    hipLaunchKernelGGL(mp_stream_scan_kernel, dim3(1), dim3(128), 0, s, a, blocks);
+    hipLaunchKernelGGL(mp_stream_scan_kernel, dim3((unsigned)(3 * a.K)), dim3(64), 0, s, a, blocks);
     hipLaunchKernelGGL(mp_stream_scatter_kernel, dim3((unsigned)blocks), dim3(kBlockTiles), 0, s, a);
     hipLaunchKernelGGL(mp_stream_dc_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, s, a);
     return (int)hipGetLastError();

@@ -221,10 +221,10 @@ struct mpc_context {
         size_t dev_bytes = 0;
         void* host = nullptr;                        // pinned
         size_t host_bytes = 0;
+        size_t tiles = 0;                            // geometry the tables inside `dev` were last cleared for
+        int K = 0;
     };
     EntropySlot ent[kSeqSlots];
-    unsigned* ent_hist = nullptr;                    // ghist | gfirst, [n_streams][65536] each
-    int ent_hist_streams = 0;
     // The pursuit of a call is cut into sub-batches that run on `pipes` internal streams, each with its own
     // workspace: the latency-bound bookkeeping kernels of one sub-batch (finish, update, bucket, fill) overlap
     // the machine-filling sweeps of the other.  Fork/join with events on the caller's stream: still no host
@@ -565,7 +565,6 @@ void mpc_context_destroy(mpc_context* c) {
             if (e.dev) (void)hipFree(e.dev);
             if (e.host) (void)hipHostFree(e.host);
         }
-        if (c->ent_hist) (void)hipFree(c->ent_hist);
         if (c->seq_up) (void)hipStreamDestroy(c->seq_up);
         if (c->seq_compute) (void)hipStreamDestroy(c->seq_compute);
         for (hipStream_t sd : c->seq_down)
@@ -1147,7 +1146,6 @@ bool host_entropy_forced() {
 
 struct EntropyBuffers {
     mpc::EntropyArgs args{};
-    unsigned* d_entries = nullptr;
     uint8_t* d_out = nullptr;
     size_t out_capacity = 0;             // bytes, device and host
     unsigned long long capacity_symbols = 0;
@@ -1172,7 +1170,8 @@ mpc_status entropy_buffers(mpc_context* c, int sl, size_t tiles, int K, EntropyB
     const size_t packed_b = up(sizeof(uint16_t) * 2 * n_tc * K);
     const size_t tcode_b = up(sizeof(unsigned) * 65536 * S), tlen_b = up(65536 * static_cast<size_t>(S));
     const size_t out_b = up(packed_b + 65536);
-    const size_t dev_need = streams_b + totals_b + 6 * blk_u32 + blk_u64 + 2 * triples_b + packed_b + tcode_b + tlen_b + out_b;
+    const size_t hist_b = tcode_b;                        // ghist, gfirst: [S][65536] words each
+    const size_t dev_need = streams_b + totals_b + 6 * blk_u32 + blk_u64 + packed_b + tcode_b + tlen_b + out_b + 2 * hist_b;
     const size_t host_need = streams_b + totals_b + 2 * triples_b + out_b;
     mpc_context::EntropySlot& e = c->ent[sl];
     if (dev_need > e.dev_bytes) {
@@ -1183,29 +1182,19 @@ mpc_status entropy_buffers(mpc_context* c, int sl, size_t tiles, int K, EntropyB
         const hipError_t err = hipMalloc(&e.dev, dev_need);
         if (err != hipSuccess) return fail(MPC_ERR_ALLOC, "entropy stage buffers of %zu bytes: %s", dev_need, hipGetErrorString(err));
         e.dev_bytes = dev_need;
-        // the dense code tables are zero between frames (phase 2 clears what it set)
-        HIP_TRY(hipMemset(e.dev, 0, dev_need));
+        e.tiles = 0;
     }
     if (host_need > e.host_bytes) {
         if (e.host) (void)hipHostFree(e.host);
         e.host = nullptr;
         e.host_bytes = 0;
-        const hipError_t err = hipHostMalloc(&e.host, host_need, hipHostMallocDefault);
+        const hipError_t err = hipHostMalloc(&e.host, host_need, hipHostMallocMapped);
         if (err != hipSuccess) return fail(MPC_ERR_ALLOC, "pinned entropy stage buffers of %zu bytes: %s", host_need, hipGetErrorString(err));
         e.host_bytes = host_need;
     }
-    if (c->ent_hist_streams < S) {
-        HIP_TRY(hipDeviceSynchronize());
-        if (c->ent_hist) (void)hipFree(c->ent_hist);
-        c->ent_hist = nullptr;
-        c->ent_hist_streams = 0;
-        const size_t words = static_cast<size_t>(65536) * S;
-        const hipError_t err = hipMalloc(reinterpret_cast<void**>(&c->ent_hist), 2 * words * sizeof(unsigned));
-        if (err != hipSuccess) return fail(MPC_ERR_ALLOC, "histogram tables: %s", hipGetErrorString(err));
-        HIP_TRY(hipMemset(c->ent_hist, 0, words * sizeof(unsigned)));
-        HIP_TRY(hipMemset(c->ent_hist + words, 0xFF, words * sizeof(unsigned)));
-        c->ent_hist_streams = S;
-    }
+    // the kernels read and write the small host-side tables in place (mapped, coherent host memory)
+    char* mapped = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&mapped), e.host, 0));
     char* d = static_cast<char*>(e.dev);
     char* h = static_cast<char*>(e.host);
     mpc::EntropyArgs& a = b->args;
@@ -1221,43 +1210,57 @@ mpc_status entropy_buffers(mpc_context* c, int sl, size_t tiles, int K, EntropyB
     a.blk_out = reinterpret_cast<unsigned*>(d); d += blk_u32;
     a.blk_bits = reinterpret_cast<unsigned*>(d); d += blk_u32;
     a.blk_bit_off = reinterpret_cast<unsigned long long*>(d); d += blk_u64;
-    a.triples = reinterpret_cast<unsigned*>(d); d += triples_b;
-    b->d_entries = reinterpret_cast<unsigned*>(d); d += triples_b;
     a.packed = reinterpret_cast<uint16_t*>(d); d += packed_b;
     a.tcode = reinterpret_cast<unsigned*>(d); d += tcode_b;
     a.tlen = reinterpret_cast<uint8_t*>(d); d += tlen_b;
     b->d_out = reinterpret_cast<uint8_t*>(d); d += out_b;
     a.triple_cap = kTripleCap;
-    a.ghist = c->ent_hist;
-    a.gfirst = c->ent_hist + static_cast<size_t>(65536) * c->ent_hist_streams;
-    a.entries = b->d_entries;
+    a.ghist = reinterpret_cast<unsigned*>(d); d += hist_b;
+    a.gfirst = reinterpret_cast<unsigned*>(d); d += hist_b;     // the last hist_b bytes of the allocation
     a.out32 = reinterpret_cast<unsigned*>(b->d_out);
+    if (e.tiles != tiles || e.K != K) {
+        // the dense code tables and the histogram are zero between frames (the kernels clear what they set), the first
+        // positions all ones; a slot carved for another geometry holds them elsewhere
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemset(a.tcode, 0, tcode_b));
+        HIP_TRY(hipMemset(a.tlen, 0, tlen_b));
+        HIP_TRY(hipMemset(a.ghist, 0, hist_b));
+        HIP_TRY(hipMemset(a.gfirst, 0xFF, hist_b));
+        e.tiles = tiles;
+        e.K = K;
+    }
     b->out_capacity = out_b;
     b->capacity_symbols = cap_symbols;
-    b->h_streams = reinterpret_cast<mpc::EntStream*>(h); h += streams_b;
-    b->h_totals = reinterpret_cast<unsigned*>(h); h += totals_b;
-    b->h_triples = reinterpret_cast<unsigned*>(h); h += triples_b;
-    b->h_entries = reinterpret_cast<unsigned*>(h); h += triples_b;
+    b->h_streams = reinterpret_cast<mpc::EntStream*>(h); a.host_streams = reinterpret_cast<mpc::EntStream*>(mapped + (h - static_cast<char*>(e.host))); h += streams_b;
+    b->h_totals = reinterpret_cast<unsigned*>(h); a.host_totals = reinterpret_cast<unsigned*>(mapped + (h - static_cast<char*>(e.host))); h += totals_b;
+    b->h_triples = reinterpret_cast<unsigned*>(h); a.triples = reinterpret_cast<unsigned*>(mapped + (h - static_cast<char*>(e.host))); h += triples_b;
+    b->h_entries = reinterpret_cast<unsigned*>(h); a.entries = reinterpret_cast<const unsigned*>(mapped + (h - static_cast<char*>(e.host))); h += triples_b;
     b->h_out = reinterpret_cast<uint8_t*>(h); h += out_b;
     return MPC_OK;
 }
 
 enum class EntropyResult { kDone, kNeedsHost, kFailed };
 
-// The host's part and phase 2, on `s` (phase 1 has completed).  kNeedsHost: nothing written, take the host route.
+double trace_ms() {
+    static const auto origin = std::chrono::steady_clock::now();
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - origin).count();
+}
+
+// The host's part and phase 2.  Phase 1 has completed (the caller waited for an event behind it): the statistics are in the
+// slot's host mirrors.  Everything is enqueued on `s` in order -- table import, the code kernels, the container's way to
+// the host -- and `enqueued()` (if any) is called once that is done (or once it is clear that nothing will be enqueued);
+// then this thread waits for `done` and patches the host's pieces in.  kNeedsHost: nothing written, take the host route.
 EntropyResult finish_entropy_on_device(const EntropyBuffers& b, int device_block_size, int width, int height, int K, const double* quant,
-                                       hipStream_t s, uint8_t** blob, size_t* nbytes) {
+                                       hipStream_t s, hipEvent_t done, const std::function<void()>& enqueued, uint8_t** blob,
+                                       size_t* nbytes, double* stamps = nullptr) {
     const mpc::EntropyArgs& a = b.args;
+    auto stamp = [&](int i) { if (stamps) stamps[i] = trace_ms(); };
+    bool told = false;
+    auto tell = [&] { if (!told && enqueued) enqueued(); told = true; };
+    struct TellOnExit { decltype(tell)& f; ~TellOnExit() { f(); } } tell_on_exit{tell};
     const int S = a.n_streams;
-    if (hipMemcpyAsync(b.h_streams, a.streams, sizeof(mpc::EntStream) * S, hipMemcpyDeviceToHost, s) != hipSuccess ||
-        hipMemcpyAsync(b.h_totals, a.totals, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, s) != hipSuccess ||
-        hipStreamSynchronize(s) != hipSuccess)
-        return EntropyResult::kFailed;
     if (b.h_totals[3] != 0 || b.h_totals[2] > kTripleCap) return EntropyResult::kNeedsHost;
-    const unsigned n_triples = b.h_totals[2];
-    if (n_triples && (hipMemcpyAsync(b.h_triples, a.triples, sizeof(unsigned) * 3 * n_triples, hipMemcpyDeviceToHost, s) != hipSuccess ||
-                      hipStreamSynchronize(s) != hipSuccess))
-        return EntropyResult::kFailed;
+    stamp(0);
     std::vector<mpc::StreamPlan> plans(static_cast<size_t>(S));
     mpc::parallel_jobs(S, [&](int j) {
         const mpc::EntStream& st = b.h_streams[j];
@@ -1290,17 +1293,16 @@ EntropyResult finish_entropy_on_device(const EntropyBuffers& b, int device_block
             b.h_entries[at++] = e[k + 2];
         }
     }
+    stamp(1);                                                   // tables built
     mpc::EntropyArgs a2 = a;
     a2.n_entries = static_cast<unsigned>(n_entries);
     a2.out_words = out_words;
-    if (hipMemcpyAsync(a.streams, b.h_streams, sizeof(mpc::EntStream) * S, hipMemcpyHostToDevice, s) != hipSuccess ||
-        (n_entries && hipMemcpyAsync(b.d_entries, b.h_entries, sizeof(unsigned) * 3 * n_entries, hipMemcpyHostToDevice, s) != hipSuccess) ||
-        hipMemsetAsync(b.d_out, 0, out_words * 4, s) != hipSuccess ||
-        mpc::launch_entropy_phase2(a2, raw_symbols, s) != 0 ||
-        hipMemcpyAsync(b.h_out, b.d_out, out_words * 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
-        hipMemcpyAsync(b.h_streams, a.streams, sizeof(mpc::EntStream) * S, hipMemcpyDeviceToHost, s) != hipSuccess ||
-        hipStreamSynchronize(s) != hipSuccess)
-        return EntropyResult::kFailed;
+    const bool ok = hipMemsetAsync(b.d_out, 0, out_words * 4, s) == hipSuccess && mpc::launch_entropy_phase2(a2, raw_symbols, s) == 0 &&
+                    hipMemcpyAsync(b.h_out, b.d_out, out_words * 4, hipMemcpyDeviceToHost, s) == hipSuccess &&
+                    hipEventRecord(done, s) == hipSuccess;
+    tell();
+    if (!ok || hipEventSynchronize(done) != hipSuccess) return EntropyResult::kFailed;
+    stamp(2);                                                   // codes written, bytes on the host
     for (int j = 0; j < S; ++j)                                 // the device wrote exactly the bits the tables promise
         if (b.h_streams[j].coded_bits != plans[static_cast<size_t>(j)].payload_bits) return EntropyResult::kFailed;
     mpc::or_bits(b.h_out, 0, head);
@@ -1350,21 +1352,24 @@ static mpc_status encode_sequence(mpc_context* c, const uint8_t* const* frames, 
     const size_t dev_slot = (on_device ? 0 : up(img_bytes)) + counts_bytes + choices_bytes + live_bytes + sizes_bytes + off_bytes + symbols_bytes + dc_bytes;
     constexpr size_t S = mpc_context::kSeqSlots;
     const size_t slots = std::min<size_t>(S, static_cast<size_t>(n_frames));
-    if (slots * host_slot > c->host_stage_bytes) {
+    // a sequence gets every slot's buffers at once: a later, longer call then finds them (allocating pinned memory takes
+    // tens of milliseconds)
+    const size_t alloc_slots = n_frames > 1 ? S : 1;
+    if (alloc_slots * host_slot > c->host_stage_bytes) {
         if (c->host_stage) (void)hipHostFree(c->host_stage);
         c->host_stage = nullptr;
         c->host_stage_bytes = 0;
-        const hipError_t e = hipHostMalloc(&c->host_stage, slots * host_slot, hipHostMallocDefault);
-        if (e != hipSuccess) return fail(MPC_ERR_ALLOC, "pinned staging of %zu bytes: %s", slots * host_slot, hipGetErrorString(e));
-        c->host_stage_bytes = slots * host_slot;
+        const hipError_t e = hipHostMalloc(&c->host_stage, alloc_slots * host_slot, hipHostMallocDefault);
+        if (e != hipSuccess) return fail(MPC_ERR_ALLOC, "pinned staging of %zu bytes: %s", alloc_slots * host_slot, hipGetErrorString(e));
+        c->host_stage_bytes = alloc_slots * host_slot;
     }
-    if (slots * dev_slot > c->stage_bytes) {
+    if (alloc_slots * dev_slot > c->stage_bytes) {
         if (c->stage) (void)hipFree(c->stage);
         c->stage = nullptr;
         c->stage_bytes = 0;
-        const hipError_t e = hipMalloc(&c->stage, slots * dev_slot);
-        if (e != hipSuccess) return fail(MPC_ERR_ALLOC, "device staging of %zu bytes: %s", slots * dev_slot, hipGetErrorString(e));
-        c->stage_bytes = slots * dev_slot;
+        const hipError_t e = hipMalloc(&c->stage, alloc_slots * dev_slot);
+        if (e != hipSuccess) return fail(MPC_ERR_ALLOC, "device staging of %zu bytes: %s", alloc_slots * dev_slot, hipGetErrorString(e));
+        c->stage_bytes = alloc_slots * dev_slot;
     }
     if (!c->seq_up) {
         HIP_TRY(hipStreamCreateWithFlags(&c->seq_up, hipStreamNonBlocking));
@@ -1377,9 +1382,18 @@ static mpc_status encode_sequence(mpc_context* c, const uint8_t* const* frames, 
     HIP_TRY(ensure_workspace(c, static_cast<long long>(n_tc)) == MPC_OK ? hipSuccess : hipErrorOutOfMemory);
     const double* q = quant ? quant : c->quant.data();
     const bool device_entropy = !host_entropy_forced();
+    // ONE ordered device queue.  The pursuit kernel fills every CU for milliseconds, and nothing else gets onto the device
+    // while it runs -- not a small kernel, not a copy (short copies are blit kernels) -- so work queued beside it on another
+    // stream just waits for a gap at a time nobody controls.  Everything therefore goes to seq_compute in the order it should
+    // run: pursuit(f), stream assembly(f), entropy phase 1(f) from this thread; phase 2(f) and the container's copy from the
+    // frame's worker once it has built the tables -- which happens while pursuit(f + 1) runs; pursuit(f + 2) is enqueued only
+    // after that (`phase2_enqueued`), so that it cannot slip in front.  The statistics reach the host through mapped memory
+    // written by the kernels themselves, the host waits on events only.
+    hipStream_t pursuit_stream = c->seq_compute;
+    std::future<void> phase2_enqueued[S];
     EntropyBuffers ent[S];
     if (device_entropy)
-        for (size_t sl = 0; sl < slots; ++sl) {
+        for (size_t sl = 0; sl < alloc_slots; ++sl) {
             const mpc_status es = entropy_buffers(c, static_cast<int>(sl), tiles, K, &ent[sl]);
             if (es != MPC_OK) return es;
         }
@@ -1410,6 +1424,7 @@ static mpc_status encode_sequence(mpc_context* c, const uint8_t* const* frames, 
         Pending& slot = pending[sl];
         collect(slot);                    // frame f - slots is done with this slot: its download and its entropy stage have finished
         if (st != MPC_OK) break;
+        if (f >= 2 && phase2_enqueued[(f - 2) % static_cast<int>(slots)].valid()) phase2_enqueued[(f - 2) % static_cast<int>(slots)].get();
         char* dbase = static_cast<char*>(c->stage) + static_cast<size_t>(sl) * dev_slot;
         char* hbase = static_cast<char*>(c->host_stage) + static_cast<size_t>(sl) * host_slot;
         const uint8_t* d_rgb = frames[f];
@@ -1433,7 +1448,7 @@ static mpc_status encode_sequence(mpc_context* c, const uint8_t* const* frames, 
                 if (parts[k].valid()) parts[k].get();
             MPC_SEQ_TRY(hipMemcpyAsync(d_img, pinned_rgb, img_bytes, hipMemcpyHostToDevice, c->seq_up));
             MPC_SEQ_TRY(hipEventRecord(c->seq_events[sl][0], c->seq_up));
-            MPC_SEQ_TRY(hipStreamWaitEvent(c->seq_compute, c->seq_events[sl][0], 0));
+            MPC_SEQ_TRY(hipStreamWaitEvent(pursuit_stream, c->seq_events[sl][0], 0));
             d_rgb = d_img;
         }
         uint16_t* d_counts = reinterpret_cast<uint16_t*>(dbase);
@@ -1452,20 +1467,22 @@ static mpc_status encode_sequence(mpc_context* c, const uint8_t* const* frames, 
         unsigned long long* off = reinterpret_cast<unsigned long long*>(hbase + counts_bytes);
         uint16_t* symbols = reinterpret_cast<uint16_t*>(hbase + counts_bytes + off_bytes);
         st = mpc_encode_tiles_device(c, d_rgb, width, height, static_cast<size_t>(3) * width, 0, tiles_y, quant, d_counts, d_choices,
-                                     nullptr, nullptr, 0, c->seq_compute);
+                                     nullptr, nullptr, 0, pursuit_stream);
         if (st != MPC_OK) break;
-        MPC_SEQ_TRY(static_cast<hipError_t>(mpc::launch_stream_assembly(sa, c->seq_compute)));
+        hipStream_t down = c->seq_down[sl];       // the host route's copies
+        MPC_SEQ_TRY(static_cast<hipError_t>(mpc::launch_stream_assembly(sa, pursuit_stream)));
         EntropyBuffers eb = ent[sl];
         if (device_entropy) {
             eb.args.counts = d_counts;
             eb.args.symbols = sa.symbols;
             eb.args.stream_off = sa.stream_off;
-            MPC_SEQ_TRY(static_cast<hipError_t>(mpc::launch_entropy_phase1(eb.args, eb.capacity_symbols, c->seq_compute)));
+            MPC_SEQ_TRY(static_cast<hipError_t>(mpc::launch_entropy_phase1(eb.args, eb.capacity_symbols, pursuit_stream)));
         }
         hipEvent_t ev_comp = c->seq_events[sl][1];
-        MPC_SEQ_TRY(hipEventRecord(ev_comp, c->seq_compute));
+        MPC_SEQ_TRY(hipEventRecord(ev_comp, pursuit_stream));
+        auto told = std::make_shared<std::promise<void>>();
+        phase2_enqueued[sl] = told->get_future();
         const int bs = c->block_size, device = c->device;
-        hipStream_t down = c->seq_down[sl];
         const uint16_t* d_symbols = sa.symbols;
         const unsigned long long* d_off = sa.stream_off;
         const size_t n_off = 6 * static_cast<size_t>(K) + 1;
@@ -1473,24 +1490,33 @@ static mpc_status encode_sequence(mpc_context* c, const uint8_t* const* frames, 
         // the slot's worker: wait for the device, fetch the stream boundaries, then exactly the live symbols, then code them
         hipEvent_t ev_down = c->seq_events[sl][2];
         static const bool trace = env_int("MPC_TRACE", 0) != 0;
-        static const auto t_origin = std::chrono::steady_clock::now();
-        auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_origin).count(); };
+        auto now_ms = [] { return trace_ms(); };
         const double t_enq = now_ms();
         slot.result = std::async(std::launch::async, [=]() -> std::pair<uint8_t*, size_t> {
             struct Trace {
-                bool on; int f; double t0, t1 = 0, t2 = 0, t3 = 0;
-                ~Trace() { if (on) std::fprintf(stderr, "[trace] frame %d enqueued %.2f | device done %.2f | symbols on host %.2f | coded %.2f\n", f, t0, t1, t2, t3); }
+                bool on; int f; double t0, t1 = 0, t2 = 0, t3 = 0, e[3] = {0, 0, 0};
+                ~Trace() {
+                    if (on) std::fprintf(stderr, "[trace] frame %d enqueued %.2f | device done %.2f | symbols on host %.2f | coded %.2f | entropy: stats %.2f tables %.2f bytes %.2f\n",
+                                         f, t0, t1, t2, t3, e[0], e[1], e[2]);
+                }
             } tr{trace, f, t_enq};
+            struct Tell {                                      // whatever happens, the enqueuing thread is released once
+                std::shared_ptr<std::promise<void>> p;
+                bool done = false;
+                void operator()() { if (!done) p->set_value(); done = true; }
+                ~Tell() { (*this)(); }
+            } tell{told};
             if (hipSetDevice(device) != hipSuccess || hipEventSynchronize(ev_comp) != hipSuccess) return {nullptr, 0};
             tr.t1 = now_ms();
             if (device_entropy) {
                 uint8_t* blob = nullptr;
                 size_t n = 0;
-                const EntropyResult r = finish_entropy_on_device(eb, bs, width, height, K, q, down, &blob, &n);
+                const EntropyResult r = finish_entropy_on_device(eb, bs, width, height, K, q, pursuit_stream, ev_down, [&] { tell(); }, &blob, &n, tr.e);
                 tr.t2 = tr.t3 = now_ms();
                 if (r == EntropyResult::kDone) return {blob, n};
                 if (r == EntropyResult::kFailed) return {nullptr, 0};
             }
+            tell();
             if (hipMemcpyAsync(off, d_off, sizeof(unsigned long long) * n_off, hipMemcpyDeviceToHost, down) != hipSuccess) return {nullptr, 0};
             if (hipMemcpyAsync(counts, d_counts, sizeof(uint16_t) * n_tc, hipMemcpyDeviceToHost, down) != hipSuccess) return {nullptr, 0};
             if (hipEventRecord(ev_down, down) != hipSuccess || hipEventSynchronize(ev_down) != hipSuccess) return {nullptr, 0};
@@ -1508,7 +1534,8 @@ static mpc_status encode_sequence(mpc_context* c, const uint8_t* const* frames, 
 #undef MPC_SEQ_TRY
     for (int f = n_frames; f < n_frames + static_cast<int>(slots); ++f) collect(pending[f % static_cast<int>(slots)]);   // oldest first
     (void)hipStreamSynchronize(c->seq_up);
-    (void)hipStreamSynchronize(c->seq_compute);
+    (void)hipStreamSynchronize(pursuit_stream);
+    for (size_t sl = 0; sl < slots; ++sl) (void)hipStreamSynchronize(c->seq_down[sl]);
     if (st != MPC_OK) {
         for (int f = 0; f < n_frames; ++f) { std::free(bytes[f]); bytes[f] = nullptr; nbytes[f] = 0; }
     }
@@ -1577,7 +1604,11 @@ mpc_status mpc_records_to_container_device(mpc_context* c, const uint16_t* d_cou
         eb.args.stream_off = sa.stream_off;
         const int e1 = mpc::launch_entropy_phase1(eb.args, eb.capacity_symbols, s);
         if (e1 != 0) return fail(MPC_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(e1)));
-        const EntropyResult r = finish_entropy_on_device(eb, c->block_size, width, height, K, quant ? quant : c->quant.data(), s, bytes, nbytes);
+        HIP_TRY(hipStreamSynchronize(s));
+        hipEvent_t done = nullptr;
+        HIP_TRY(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+        const EntropyResult r = finish_entropy_on_device(eb, c->block_size, width, height, K, quant ? quant : c->quant.data(), s, done, nullptr, bytes, nbytes);
+        (void)hipEventDestroy(done);
         if (r == EntropyResult::kDone) return MPC_OK;
         if (r == EntropyResult::kFailed) return fail(MPC_ERR_HIP, "device entropy stage failed: %s", hipGetErrorString(hipGetLastError()));
     }
@@ -1633,7 +1664,10 @@ mpc_status mpc_code_symbol_streams_device(mpc_context* c, int width, int height,
         const int e1 = mpc::launch_entropy_phase1(eb.args, eb.capacity_symbols, nullptr);
         if (e1 != 0) return fail(MPC_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(e1)));
         HIP_TRY(hipStreamSynchronize(nullptr));
-        const EntropyResult r = finish_entropy_on_device(eb, c->block_size, width, height, K, q, nullptr, bytes, nbytes);
+        hipEvent_t done = nullptr;
+        HIP_TRY(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+        const EntropyResult r = finish_entropy_on_device(eb, c->block_size, width, height, K, q, nullptr, done, nullptr, bytes, nbytes);
+        (void)hipEventDestroy(done);
         HIP_TRY(hipDeviceSynchronize());
         if (r == EntropyResult::kDone) {
             if (route) *route = 0;
