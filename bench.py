@@ -147,6 +147,9 @@ def main():
     ap.add_argument("--workload", default="raise", choices=sorted(WORKLOADS))
     ap.add_argument("--quality", type=float, default=None, help="bpp allocation (BASELINE configs[2] sweeps 2.0 .. 6.0); default 3.5")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--fast", action="store_true",
+                    help="the `...Fast` (float) flavour of the tile path (SURVEY 8f N3): NOT the driver's line -- parity unpinned "
+                         "against the reference, bit-identical to oracle/mpo_fast.c only")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="target duration of each CPU sample")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo + --share-device rehearses the N>1 path on a one-GPU box")
@@ -179,6 +182,8 @@ def main():
     if args.quality is not None:
         q = args.quality
     ctx = ia.create_compression_context(K, 8, q, device=local_rank)
+    if args.fast:
+        ctx.set_fast(True)
     tiles_x, tiles_y = (W + 7) // 8, (H + 7) // 8
     frames = world                                           # weak scaling: N frames per step for N ranks
     host_frames = np.stack([synth_frame(W, H, 12345 + f) for f in range(frames)])
@@ -298,12 +303,16 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": "f32" if args.fast else "f64",
             "data": "synthetic",
             "config": {"workload": f"{frames} x {W}x{H} synthetic RGB (mt19937 seed 12345+f), quality {q}, K={K} "
                                    "atoms/tile-channel, 8x8 tiles" + (f", row-striped over {world} GPUs" if world > 1 else ""),
-                       "stage": "frames resident in HBM -> tile encode + stream assembly on the device -> live symbols to the host -> "
-                                "entropy stage -> container bytes (byte-identical to the reference's encodeImage)"
+                       "stage": "frames resident in HBM -> tile encode, stream assembly and the per-symbol work of the entropy stage "
+                                "(run lengths, histograms, code writing) on the device; the host builds one code table per stream -> "
+                                "container bytes "
+                                + ("(the ...Fast / float flavour: PARITY UNPINNED against the reference's Eigen results; bit-identical to "
+                                   "oracle/mpo_fast.c, PSNR / size equivalent to the double path)" if args.fast else
+                                   "(byte-identical to the reference's encodeImage)")
                                 + ("; stripes' records exchanged between ranks so that rank f produces frame f's container" if world > 1 else
                                    "; the steps of the timed region are pipelined (entropy stage of step i beside the device work of step i+1)"),
                        "container_bytes": container_bytes, "bpp": round(8.0 * container_bytes / (W * H), 4)},
@@ -312,7 +321,7 @@ def main():
             "roofline": roof,
         }
         if not args.no_cpu and world == 1:
-            line["cpu_baseline"] = cpu_baseline(W, H, K, q, host_frames[0], args.cpu_seconds)
+            line["cpu_baseline"] = cpu_baseline(W, H, K, q, host_frames[0], args.cpu_seconds)      # the double oracle, either way
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -20,12 +20,15 @@
 // dictionary of that channel the same device path is used, otherwise the call fails like the reference fails, with a thrown
 // std::range_error*.
 //
-// The Fast names (Eigen, float) are served by the SAME double-exact device path: their results are those of the reference's
-// double functions, not of its float ones (which depend on Eigen's summation order).  Build with -DMPC_DROPIN_NO_EIGEN in a
-// tree without Eigen to leave them out.
+// The Fast names (Eigen, float) run the float flavour of the device path (mpc_context_set_fast): the reference's Fast
+// statements in float on the dictionary rounded to float -- equivalent to the double path in PSNR and size, identical to
+// oracle/mpo_fast.c, NOT pinned to the reference's own float results (those depend on Eigen's summation order and on its float
+// eigensolver; see include/mpcodec.h).  MPC_FAST_EXACT=1 serves them from the double path instead.  Build with
+// -DMPC_DROPIN_NO_EIGEN in a tree without Eigen to leave them out.
 #include "CompressedImage.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -50,10 +53,14 @@ int device_ordinal() {
 struct Handles {
     std::mutex lock;
     std::map<std::pair<size_t, size_t>, mpc_context*> by_shape;
-    mpc_context* get(size_t K, size_t blockSize) {
+    // fast: the float flavour (its own context: the flag is per context; the device dictionary is shared anyway)
+    mpc_context* get(size_t K, size_t blockSize, bool fast = false) {
         std::lock_guard<std::mutex> hold(lock);
-        mpc_context*& h = by_shape[{K, blockSize}];
-        if (!h) check(mpc_context_create(static_cast<int>(K), static_cast<int>(blockSize), 3.5, device_ordinal(), &h));
+        mpc_context*& h = by_shape[{2 * K + (fast ? 1 : 0), blockSize}];
+        if (!h) {
+            check(mpc_context_create(static_cast<int>(K), static_cast<int>(blockSize), 3.5, device_ordinal(), &h));
+            if (fast) check(mpc_context_set_fast(h, 1));
+        }
         return h;
     }
     ~Handles() {
@@ -157,14 +164,14 @@ void require_standard(const matching::DynamicDictionaryFunction& y, const matchi
 }
 
 std::unique_ptr<uint8_t[]> encode(const img::image<img::rgb>* imgIn, size_t K, size_t blockSize, const double* qY, const double* qU,
-                                  const double* qV, size_t& outputByteSize) {
+                                  const double* qV, size_t& outputByteSize, bool fast = false) {
     std::vector<double> q(3 * K);
     std::memcpy(q.data(), qY, K * sizeof(double));
     std::memcpy(q.data() + K, qU, K * sizeof(double));
     std::memcpy(q.data() + 2 * K, qV, K * sizeof(double));
     uint8_t* bytes = nullptr;
     size_t n = 0;
-    check(mpc_encode_image(handles().get(K, blockSize), reinterpret_cast<const uint8_t*>(imgIn->data), static_cast<int>(imgIn->width()),
+    check(mpc_encode_image(handles().get(K, blockSize, fast), reinterpret_cast<const uint8_t*>(imgIn->data), static_cast<int>(imgIn->width()),
                            static_cast<int>(imgIn->height()), q.data(), &bytes, &n));
     std::unique_ptr<uint8_t[]> out = std::make_unique<uint8_t[]>(n ? n : 1);
     std::memcpy(out.get(), bytes, n);
@@ -173,12 +180,12 @@ std::unique_ptr<uint8_t[]> encode(const img::image<img::rgb>* imgIn, size_t K, s
     return out;
 }
 
-std::unique_ptr<img::image<img::rgb>> decode(const uint8_t bytes[], size_t byteSize) {
+std::unique_ptr<img::image<img::rgb>> decode(const uint8_t bytes[], size_t byteSize, bool fast = false) {
     if (byteSize < 14) throw new std::range_error("Invalid input data");
     const size_t blockSize = bytes[13];                   // header: magic, width, height (3 x u32), K (u8), block size (u8)
     uint8_t* rgb = nullptr;
     int w = 0, h = 0;
-    check(mpc_decode_image(handles().get(32, blockSize ? blockSize : 8), bytes, byteSize, &rgb, &w, &h));
+    check(mpc_decode_image(handles().get(32, blockSize ? blockSize : 8, fast), bytes, byteSize, &rgb, &w, &h));
     std::unique_ptr<img::image<img::rgb>> out = std::make_unique<img::image<img::rgb>>(static_cast<size_t>(w), static_cast<size_t>(h), false);
     std::memcpy(static_cast<void*>(out->data), rgb, static_cast<size_t>(w) * h * 3);
     mpc_free(rgb);
@@ -296,6 +303,10 @@ int identify_fast(const matching::DynamicDictionaryFunctionFast& dyn, size_t blo
     const StandardDynamicFast* mine = dyn.target<StandardDynamicFast>();
     return mine && mine->blockSize == blockSize ? mine->channel : -1;
 }
+bool fast_flavour() {
+    const char* v = std::getenv("MPC_FAST_EXACT");
+    return !(v && *v && std::atoi(v) != 0);
+}
 std::vector<double> widen(const Eigen::VectorXf& v) {
     std::vector<double> out(static_cast<size_t>(v.size()));
     for (Eigen::Index i = 0; i < v.size(); ++i) out[static_cast<size_t>(i)] = static_cast<double>(v[i]);
@@ -339,10 +350,10 @@ std::unique_ptr<uint8_t[]> encodeImageFast(const img::image<img::rgb>* imgIn, co
     if (identify_fast(dynamicY, blockSize) != 0 || identify_fast(dynamicU, blockSize) != 1 || identify_fast(dynamicV, blockSize) != 2)
         throw new std::range_error("encodeImageFast: the dynamic dictionaries are not createCompressionContextFast's");
     const std::vector<double> qY = widen(quantY), qU = widen(quantU), qV = widen(quantV);
-    return encode(imgIn, K, blockSize, qY.data(), qU.data(), qV.data(), outputByteSize);
+    return encode(imgIn, K, blockSize, qY.data(), qU.data(), qV.data(), outputByteSize, fast_flavour());
 }
 
-std::unique_ptr<img::image<img::rgb>> decodeImageFast(const uint8_t bytes[], size_t byteSize) { return decode(bytes, byteSize); }
+std::unique_ptr<img::image<img::rgb>> decodeImageFast(const uint8_t bytes[], size_t byteSize) { return decode(bytes, byteSize, fast_flavour()); }
 
 }  // namespace compressed
 
@@ -357,7 +368,7 @@ int CalcMPDynamicFast(int K, const Eigen::VectorXf& quantization, std::vector<Ba
     if (results.size() < static_cast<size_t>(K)) results.resize(static_cast<size_t>(K));
     const std::vector<double> q = widen(quantization), in = widen(input);
     int count = 0;
-    check(mpc_calc_mp(handles().get(static_cast<size_t>(K), blockSize), channel, q.data(), in.data(),
+    check(mpc_calc_mp(handles().get(static_cast<size_t>(K), blockSize, fast_flavour()), channel, q.data(), in.data(),
                       reinterpret_cast<mpc_basis_choice*>(results.data()), &count));
     return count;
 }

@@ -58,6 +58,9 @@ def load_library():
     for f in ("K", "block_size", "num_base", "detail_rows", "device", "max_waves"):
         getattr(L, "mpc_context_" + f).argtypes = [vp]
         getattr(L, "mpc_context_" + f).restype = C.c_int
+    L.mpc_context_set_fast.argtypes = [vp, C.c_int]
+    L.mpc_context_is_fast.argtypes = [vp]
+    L.mpc_context_is_fast.restype = C.c_int
     L.mpc_context_get_quant.argtypes = [vp, _dp]
     L.mpc_context_set_quant.argtypes = [vp, _dp]
     L.mpc_context_get_dictionary.argtypes = [vp, _dp, _i32p, _dp, _dp, _dp]
@@ -388,6 +391,15 @@ class CompressionContext:
             pass
 
     # -- tables ----------------------------------------------------------------------------------
+    def set_fast(self, on=True):
+        """mpc_context_set_fast: the `...Fast` (float) flavour of the tile path for every later encode / decode of this context."""
+        _check(self.L.mpc_context_set_fast(self.h, 1 if on else 0))
+        return self
+
+    @property
+    def fast(self):
+        return bool(self.L.mpc_context_is_fast(self.h))
+
     @property
     def quant(self):
         q = np.zeros((3, self.K), np.float64)

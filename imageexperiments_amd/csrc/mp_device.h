@@ -40,6 +40,8 @@ struct DictDevice {
     int num_base;                    // 510
     int base_rows_padded;
     const double* detail;            // [3][detail_rows][64] row-major (+1 zero row at the very end)
+    const float* base32;             // the same two, rounded to float (the `...Fast` flavour)
+    const float* detail32;
     long long detail_rows;           // rows per channel (31 622)
     const int32_t* block_rows;       // [num_base]
     int block0_rows;                 // block_rows[0] (host copy)
@@ -129,6 +131,7 @@ struct DecodeParams {
     int width, height, tiles_x, tiles_y;
     uint8_t* rgb;                    // [height][width][3] (device)
     int* error_flag;                 // set to 1 if a record indexes outside its dynamic dictionary
+    int fast;                        // != 0: FromCoeffsDynamicFast (float)
 };
 int launch_decode(const DictDevice& dict, const DecodeParams& p, void* stream);
 
@@ -147,6 +150,10 @@ struct PursuitArgs {
     const int32_t* block_row_off;
     const double* quant;             // [3][K] (device)
     int K, num_base, rows0;
+    // float flavour (`...Fast`): the same dictionary rounded to float, row layout as base / detail; fast != 0 selects it
+    const float* base32;
+    const float* detail32[3];
+    int fast;
     // One launch covers all channels: workgroups [0, wg[0]) take channel 0's units, the next wg[1] channel 1's, then channel 2's
     // (a workgroup's LDS holds DetailBasis[0] of ONE channel).  Vector mode: only `vec_channel` has workgroups.
     int wg[3];

@@ -1409,8 +1409,14 @@ __global__ __launch_bounds__(256) void mp_histogram_kernel(const HistParams p, i
 // the encoder (base rows, then DetailBasis[choice] of every earlier base choice, repeats included,
 // CompressedImage.cpp:219-248).  Then RGBFromYUV (misc.cpp:28-36): round half away, clamp, store.
 // --------------------------------------------------------------------------------------------------
+// T = float: FromCoeffsDynamicFast (MatchingPursuit.cpp:130-147) on the dictionary rounded to float; RGBFromYUV on the floats
+// widened to double (CompressedImage.cpp:877-881).
+template <class T>
 __global__ __launch_bounds__(64) void mp_decode_kernel(const DictDevice dict, const DecodeParams p)
 {
+    constexpr bool kFast = std::is_same<T, float>::value;
+    const T* const base_rows = reinterpret_cast<const T*>(kFast ? static_cast<const void*>(dict.base32) : static_cast<const void*>(dict.base));
+    const T* const detail_rows = reinterpret_cast<const T*>(kFast ? static_cast<const void*>(dict.detail32) : static_cast<const void*>(dict.detail));
     const int lane = threadIdx.x;
     const long long tiles = (long long)p.tiles_x * p.tiles_y;
     for (long long t = blockIdx.x; t < tiles; t += gridDim.x) {
@@ -1418,7 +1424,7 @@ __global__ __launch_bounds__(64) void mp_decode_kernel(const DictDevice dict, co
         for (int ch = 0; ch < 3; ++ch) {
             const int count = p.counts[t * 3 + ch];
             const uint32_t* rec = p.choices + (t * 3 + ch) * p.K;
-            double acc = 0.0;
+            T acc = 0;
             int choice = 0;
             for (int i = 0; i < count && i < p.K; ++i) {
                 const uint32_t r = rec[i];
@@ -1426,12 +1432,12 @@ __global__ __launch_bounds__(64) void mp_decode_kernel(const DictDevice dict, co
                 const int d = (int)((delta >> 1) ^ (0u - (delta & 1u)));
                 choice = (i > 0) ? choice + d : (int)delta;
                 const int q = (int)((zz >> 1) ^ (0u - (zz & 1u)));
-                const double coeff = p.quant[ch * p.K + i] * (double)q;
+                const T coeff = (T)p.quant[ch * p.K + i] * (T)q;
                 // locate row `choice` in the dynamic dictionary of this tile-channel; the reference builds it from
                 // ALL `count` choices before summing (FromCoeffsDynamic :111), so resolve against the full list
-                const double* row = nullptr;
+                const T* row = nullptr;
                 if (choice >= 0 && choice < dict.num_base) {
-                    row = dict.base + (long long)choice * N;
+                    row = base_rows + (long long)choice * N;
                 } else if (choice >= dict.num_base) {
                     int off = dict.num_base;
                     int walk = 0;
@@ -1442,7 +1448,7 @@ __global__ __launch_bounds__(64) void mp_decode_kernel(const DictDevice dict, co
                         if (walk >= 0 && walk < dict.num_base) {
                             const int rows = dict.block_rows[walk];
                             if (choice < off + rows) {
-                                row = dict.detail + ((long long)ch * dict.detail_rows + dict.block_row_off[walk] + (choice - off)) * N;
+                                row = detail_rows + ((long long)ch * dict.detail_rows + dict.block_row_off[walk] + (choice - off)) * N;
                                 break;
                             }
                             off += rows;
@@ -1453,10 +1459,10 @@ __global__ __launch_bounds__(64) void mp_decode_kernel(const DictDevice dict, co
                     if (lane == 0) *p.error_flag = 1;
                     continue;
                 }
-                const double term = row[lane] * coeff;
+                const T term = row[lane] * coeff;
                 acc = acc + term;
             }
-            yuv[ch] = acc;
+            yuv[ch] = (double)acc;
         }
         const int tx = (int)(t / p.tiles_y), ty = (int)(t - (long long)tx * p.tiles_y);
         const int u = tx * 8 + (lane & 7), v = ty * 8 + (lane >> 3);          // block index = dx + 8*dy
@@ -1738,7 +1744,8 @@ int launch_decode(const DictDevice& dict, const DecodeParams& p, void* stream)
     const long long tiles = (long long)p.tiles_x * p.tiles_y;
     unsigned blocks = (unsigned)(tiles < 16384 ? tiles : 16384);
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(mp_decode_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream, dict, p);
+    if (p.fast) hipLaunchKernelGGL(mp_decode_kernel<float>, dim3(blocks), dim3(64), 0, (hipStream_t)stream, dict, p);
+    else hipLaunchKernelGGL(mp_decode_kernel<double>, dim3(blocks), dim3(64), 0, (hipStream_t)stream, dict, p);
     return (int)hipGetLastError();
 }
 

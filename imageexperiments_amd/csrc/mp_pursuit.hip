@@ -119,18 +119,24 @@ __device__ __forceinline__ double from_next32(double x)             // lanes 0..
     return __hiloint2double((int)b[1], (int)a[1]);
 }
 
+__device__ __forceinline__ float from_prev16(float x) { return __uint_as_float(__builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false)[0]); }
+__device__ __forceinline__ float from_next16(float x) { return __uint_as_float(__builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false)[1]); }
+__device__ __forceinline__ float from_prev32(float x) { return __uint_as_float(__builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false)[0]); }
+__device__ __forceinline__ float from_next32(float x) { return __uint_as_float(__builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false)[1]); }
+
 // Lane row h (= lane >> 4) holds the pixels 16 * pos(h) .. + 15 with pos = 0, 1, 3, 2: the running sum of a dot product then
 // travels row 0 -> 1 (16-lane swap) -> 3 (32-lane swap) -> 2 (16-lane swap), every hop one VALU lane swap.
 __device__ __forceinline__ int pos_of(int h) { return h ^ (h >> 1); }
 
 // Sum of the 64 terms held 16 per lane by the four lanes of a slot, in pixel order 0..63, starting from 0.0 (the reference's
 // `tot = 0; tot += l * r`, mathmatrix.cpp:436-444); the result is returned in all four lanes.
-__device__ __forceinline__ double chain_sum(const double (&term)[16], int h)
+template <class T>
+__device__ __forceinline__ T chain_sum(const T (&term)[16], int h)
 {
-    double t = 0.0;
+    T t = 0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) t += term[i];                      // pixels 0..15: meaningful in row 0
-    double u = from_prev16(t);
+    T u = from_prev16(t);
 #pragma unroll
     for (int i = 0; i < 16; ++i) u += term[i];                      // 16..31: row 1
     t = h == 1 ? u : t;
@@ -206,9 +212,26 @@ __device__ __forceinline__ void load16(double (&x)[16], const double* p)
     }
 }
 
-__device__ __forceinline__ void keep_better(double& v, int& i, int& sel, double ov, int oi, int osel)
+__device__ __forceinline__ void load16(float (&x)[16], const float* p)
 {
-    const double a = __builtin_fabs(ov), b = __builtin_fabs(v);
+    const float4* q = reinterpret_cast<const float4*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float4 v = q[i];
+        x[4 * i] = v.x;
+        x[4 * i + 1] = v.y;
+        x[4 * i + 2] = v.z;
+        x[4 * i + 3] = v.w;
+    }
+}
+
+__device__ __forceinline__ double abs_of(double x) { return __builtin_fabs(x); }
+__device__ __forceinline__ float abs_of(float x) { return __builtin_fabsf(x); }
+
+template <class T>
+__device__ __forceinline__ void keep_better(T& v, int& i, int& sel, T ov, int oi, int osel)
+{
+    const T a = abs_of(ov), b = abs_of(v);
     if (oi >= 0 && (a > b || (a == b && i >= 0 && oi < i))) {       // start: v = 0.0, i = -1: a strict '>' 0 like Select()
         v = ov; i = oi; sel = osel;
     }
@@ -231,8 +254,13 @@ __device__ __forceinline__ void keep_better(double& v, int& i, int& sel, double 
 }  // namespace
 
 // --------------------------------------------------------------------------------------------------
+// T = double: the reference's double path, bit for bit.  T = float: the `...Fast` flavour (MatchingPursuit.cpp:27-37,76-107):
+// residual, exact evaluation, quantisation and update in float on the dictionary rounded to float -- the same screen (its
+// bound covers the float chain's own rounding, 64 x 2^-24 of the same sum), the same survivors logic, the same order.
+template <class T>
 __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(const PursuitArgs a)
 {
+    constexpr bool kFast = std::is_same<T, float>::value;
 #ifdef MPC_STAMPS
     unsigned long long stamp_acc[24];
     for (int i = 0; i < 24; ++i) stamp_acc[i] = 0;
@@ -244,7 +272,9 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
     // this workgroup's channel and its index among that channel's workgroups
     const int ch = (int)blockIdx.x < a.wg[0] ? 0 : ((int)blockIdx.x < a.wg[0] + a.wg[1] ? 1 : 2);
     const int wg_local = (int)blockIdx.x - (ch == 0 ? 0 : (ch == 1 ? a.wg[0] : a.wg[0] + a.wg[1]));
-    const double* const detail = ch == 0 ? a.detail[0] : (ch == 1 ? a.detail[1] : a.detail[2]);
+    const T* const base_rows = reinterpret_cast<const T*>(kFast ? static_cast<const void*>(a.base32) : static_cast<const void*>(a.base));
+    const T* const detail = reinterpret_cast<const T*>(kFast ? static_cast<const void*>(ch == 0 ? a.detail32[0] : (ch == 1 ? a.detail32[1] : a.detail32[2]))
+                                                             : static_cast<const void*>(ch == 0 ? a.detail[0] : (ch == 1 ? a.detail[1] : a.detail[2])));
     const uint16_t* const block_tiles = ch == 0 ? a.block_tiles[0] : (ch == 1 ? a.block_tiles[1] : a.block_tiles[2]);
     const float* const gram = ch == 0 ? a.gram[0] : (ch == 1 ? a.gram[1] : a.gram[2]);
     const double* const quant = a.quant + ch * a.K;
@@ -273,7 +303,7 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
 
     unsigned n_mfma = 0, n_steps = 0;                               // executed MFMA instructions / tile-channel-steps of this wave
     int unit[kGroups], step[kGroups];
-    double r[kGroups][16];
+    T r[kGroups][16];
     TileChannel tc[kGroups];
 #pragma unroll
     for (int g = 0; g < kGroups; ++g) { unit[g] = -1; step[g] = 0; }
@@ -316,7 +346,10 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
             s.next_off = a.num_base;
             const long long ts = s.live ? t : 0;                    // loads below are unconditional: always a valid address
             if (a.vec_in) {
-                load16(r[g], a.vec_in + ts * N + pix0);
+                double in[16];
+                load16(in, a.vec_in + ts * N + pix0);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) r[g][i] = (T)in[i];
             } else {
                 const int tiles_per_frame = a.tiles_x * a.tile_rows;
                 const int frame = (int)(ts / tiles_per_frame);
@@ -337,12 +370,12 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
                     const double red = (double)px[i][0], green = (double)px[i][1], blue = (double)px[i][2];
                     const double Y = (W_R * red + W_G * green + W_B * blue);            // misc.cpp:12-21, same expression order
                     const double v = ch == 0 ? Y : (ch == 1 ? (U_SCALE * (blue - Y)) : (V_SCALE * (red - Y)));
-                    r[g][i] = (x < a.width && y < a.height) ? v : 0.0;                 // zero fill (CompressedImage.cpp:548-552)
+                    r[g][i] = (T)((x < a.width && y < a.height) ? v : 0.0);            // zero fill (CompressedImage.cpp:548-552); Fast: static_cast<float> (:601-605)
                 }
             }
             if (!s.live)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) r[g][i] = 0.0;
+                for (int i = 0; i < 16; ++i) r[g][i] = 0;
             tc[g] = s;
         });
         bool any_unit = false;
@@ -382,8 +415,8 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
             bool nzl = false;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const double d = r[g][i];
-                nzl = nzl || (d != 0.0);
+                const T d = r[g][i];
+                nzl = nzl || (d != 0);
                 const float x = (float)d;
                 ss += (double)x * (double)x;
                 const unsigned short hb = bf16_of(x);
@@ -587,11 +620,11 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
         // stands for a value in [key & mask, key * (1 + 2^-16)] (2^-14 for pairs): thresholds on keys are lowered accordingly.
         // A lane whose runner-up key also reaches the threshold may hold more than two survivors: pass 2 / rescan lists them.
         Survivors sv[kGroups];
-        float thr_b[kGroups], T[kGroups];
+        float thr_b[kGroups], Tmin[kGroups];
         bool pass2[kGroups], rescan[kGroups];
         static_for<kGroups>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
-            pass2[g] = false; rescan[g] = false; thr_b[g] = 0.0f; T[g] = 0.0f;
+            pass2[g] = false; rescan[g] = false; thr_b[g] = 0.0f; Tmin[g] = 0.0f;
             if (unit[g] < 0) return;
             const bool has0 = tc[g].has0, hasp = tc[g].npairs > 0;
             const float top_b = __uint_as_float(__float_as_uint(reduce4_max(tb[g].k1)) & kKeepRow);
@@ -601,9 +634,9 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
             float t = top_b - Eb[g];
             if (has0) t = fmaxf(t, top_d - Eb[g]);
             if (hasp) t = fmaxf(t, lbm);
-            T[g] = bad ? -__builtin_inff() : t;                     // every row survives: the exhaustive evaluation takes over
-            thr_b[g] = (T[g] - Eb[g]) * (1.0f - 0x1p-15f);          // for MFMA rows, on keys or values
-            const float thr_p = T[g] * (1.0f - 0x1p-13f);           // for the pairs' upper-bound keys
+            Tmin[g] = bad ? -__builtin_inff() : t;                     // every row survives: the exhaustive evaluation takes over
+            thr_b[g] = (Tmin[g] - Eb[g]) * (1.0f - 0x1p-15f);          // for MFMA rows, on keys or values
+            const float thr_p = Tmin[g] * (1.0f - 0x1p-13f);           // for the pairs' upper-bound keys
             const bool live = tc[g].live && nz[g];                 // an all-zero residual projects to 0 everywhere: index -1
             const bool vague = bad || !(thr_b[g] > 0.0f);           // zero pads and everything else would qualify
             const bool unclear_b = vague || !(tb[g].k2 < thr_b[g]) || (has0 && !(td[g].k2 < thr_b[g]));
@@ -674,7 +707,7 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
                         const int row = 16 * t + 4 * h + v;
-                        if (row < rows && !(fabsf(vals[v]) + E < T[g])) sv[g].push((2 << 16) | (p << 11) | row);
+                        if (row < rows && !(fabsf(vals[v]) + E < Tmin[g])) sv[g].push((2 << 16) | (p << 11) | row);
                     }
                 }
             }
@@ -683,13 +716,13 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
 
         // ---- (7) exact evaluation of the survivors, one per tile-channel and round, by the four lanes of its slot; both groups'
         //      rows are in flight together and their two sums run side by side
-        double best_val[kGroups];
+        T best_val[kGroups];
         int best_idx[kGroups], best_sel[kGroups];
         int c0[kGroups], c1[kGroups], c2[kGroups], total[kGroups];
         bool exhaustive[kGroups];
 #pragma unroll
         for (int g = 0; g < kGroups; ++g) {
-            best_val[g] = 0.0; best_idx[g] = -1; best_sel[g] = 0;
+            best_val[g] = 0; best_idx[g] = -1; best_sel[g] = 0;
             c0[g] = __shfl(sv[g].count, slot);
             c1[g] = __shfl(sv[g].count, slot + 16);
             c2[g] = __shfl(sv[g].count, slot + 32);
@@ -697,10 +730,10 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
             exhaustive[g] = reduce4_add(sv[g].overflow ? 1u : 0u) != 0u;
         }
         // what a code means for this lane's tile-channel: the row's address, its dictionary index and its Gram row
-        auto resolve = [&](auto gc, int code, const double*& ptr, int& idx, int& sel) {
+        auto resolve = [&](auto gc, int code, const T*& ptr, int& idx, int& sel) {
             constexpr int g = decltype(gc)::value;
             const int seg = code >> 16, row = code & 2047;
-            if (seg == 0) { ptr = a.base + (long long)row * N; idx = row; sel = row; }
+            if (seg == 0) { ptr = base_rows + (long long)row * N; idx = row; sel = row; }
             else if (seg == 1) { ptr = detail + (long long)row * N; idx = tc[g].off0 + row; sel = a.num_base + row; }
             else {
                 const int p = (code >> 11) & 31;
@@ -713,12 +746,12 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
             }
         };
         auto evaluate2 = [&](const bool (&on)[kGroups], const int (&code)[kGroups]) {
-            const double* ptr[kGroups];
+            const T* ptr[kGroups];
             int idx[kGroups], sel[kGroups];
-            double x[kGroups][16];
+            T x[kGroups][16];
             static_for<kGroups>([&](auto gc) {
                 constexpr int g = decltype(gc)::value;
-                ptr[g] = a.base; idx[g] = -1; sel[g] = 0;
+                ptr[g] = base_rows; idx[g] = -1; sel[g] = 0;
                 if (on[g]) resolve(gc, code[g], ptr[g], idx[g], sel[g]);
             });
 #pragma unroll
@@ -727,7 +760,7 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
             for (int g = 0; g < kGroups; ++g)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) x[g][i] = x[g][i] * r[g][i];          // the reference's l * r, rounded to double
-            double p[kGroups];
+            T p[kGroups];
 #pragma unroll
             for (int g = 0; g < kGroups; ++g) p[g] = chain_sum(x[g], h);
 #pragma unroll
@@ -791,11 +824,11 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
         STAMP(9)
 
         // ---- (8) finish.  The chosen rows are requested first (the residual update needs them), then everything that stores.
-        double xrow[kGroups][16];
+        T xrow[kGroups][16];
 #pragma unroll
         for (int g = 0; g < kGroups; ++g) {
             const int sg = (unit[g] >= 0 && tc[g].live && best_idx[g] >= 0) ? best_sel[g] : 0;      // Gram row -> the row itself
-            load16(xrow[g], (sg < a.num_base ? a.base + (long long)sg * N : detail + (long long)(sg - a.num_base) * N) + pix0);
+            load16(xrow[g], (sg < a.num_base ? base_rows + (long long)sg * N : detail + (long long)(sg - a.num_base) * N) + pix0);
         }
         // delta / zig-zag, quantise, record, unlock, termination (MatchingPursuit.cpp:50-71)
         bool ended[kGroups];
@@ -816,14 +849,15 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
                 const int id = best_idx[g];
                 const unsigned delta = step[g] > 0 ? (((unsigned)(id - s.prev_id) << 1) ^ (unsigned)((id - s.prev_id) >> 31)) : (unsigned)id;
                 s.prev_id = id;
-                const double qstep = quant[step[g]];
-                const int q = (int)__builtin_round(best_val[g] / qstep);
+                const T qstep = (T)quant[step[g]];              // Fast: Eigen::VectorXf quantization
+                const T ratio = best_val[g] / qstep;
+                const int q = kFast ? (int)__builtin_roundf((float)ratio) : (int)__builtin_round((double)ratio);
                 const unsigned zz = ((unsigned)q << 1) ^ (unsigned)(q >> 31);
                 record = (delta & 0xFFFFu) | ((zz & 0xFFFFu) << 16);
                 if (q == 0) {
                     ended[g] = true; count = step[g];
                 } else {
-                    s.coeff = qstep * (double)q;
+                    s.coeff = (double)(qstep * (T)q);              // a float product is exact in the double that carries it
                     s.sel_g = best_sel[g];
                     if (step[g] + 1 == K) { ended[g] = true; count = K; }
                     else if (id < a.num_base) {                     // unlock DetailBasis[id]; a repeat is indexed, not swept again
@@ -871,16 +905,16 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
             if (upd) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const double scaled = s.coeff * xrow[g][i];
+                    const T scaled = (T)s.coeff * xrow[g][i];
                     r[g][i] = r[g][i] - scaled;
                 }
             }
             if (a.out.energy && __ballot(s.live && ended[g])) {    // diagnostic: sum of squares of the final residual, j ascending
-                double sq[16];
+                T sq[16];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) sq[i] = r[g][i] * r[g][i];
-                const double e2 = chain_sum(sq, h);
-                if (s.live && ended[g] && h == 0) a.out.energy[rec_of(unit[g])] = e2;
+                const T e2 = chain_sum(sq, h);
+                if (s.live && ended[g] && h == 0) a.out.energy[rec_of(unit[g])] = (double)e2;
             }
             if (upd && !ended[g] && h < 2) {
                 const int np = s.npairs < 4 ? s.npairs : 4;
@@ -981,7 +1015,8 @@ int launch_pursuit(const PursuitArgs& args, void* stream)
 {
     const int workgroups = args.wg[0] + args.wg[1] + args.wg[2];
     if (workgroups < 1) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(mp_pursuit_kernel, dim3((unsigned)workgroups), dim3(64 * kWaves), 0, static_cast<hipStream_t>(stream), args);
+    if (args.fast) hipLaunchKernelGGL(mp_pursuit_kernel<float>, dim3((unsigned)workgroups), dim3(64 * kWaves), 0, static_cast<hipStream_t>(stream), args);
+    else hipLaunchKernelGGL(mp_pursuit_kernel<double>, dim3((unsigned)workgroups), dim3(64 * kWaves), 0, static_cast<hipStream_t>(stream), args);
     return (int)hipGetLastError();
 }
 

@@ -78,6 +78,8 @@ struct DeviceDict {
     long long detail_rows = 0;
     double* d_base = nullptr;
     double* d_detail = nullptr;
+    float* d_base32 = nullptr;        // the same rows rounded to float (the `...Fast` flavour), same layout
+    float* d_detail32 = nullptr;
     int32_t* d_rows = nullptr;
     int32_t* d_rowoff = nullptr;
     uint16_t* d_base_f32 = nullptr;   // filter copies, k order 0 (step-synchronous kernels)
@@ -99,6 +101,7 @@ struct DeviceDict {
         (void)hipSetDevice(device);
         (void)hipDeviceSynchronize();
         (void)hipFree(d_base); (void)hipFree(d_detail); (void)hipFree(d_rows); (void)hipFree(d_rowoff);
+        (void)hipFree(d_base32); (void)hipFree(d_detail32);
         (void)hipFree(d_base_f32); (void)hipFree(d_detail_f32); (void)hipFree(d_base_t1); (void)hipFree(d_detail_t1);
         (void)hipFree(d_shadow); (void)hipFree(d_gram); (void)hipFree(queues); (void)hipFree(stats);
         for (int ch = 0; ch < 3; ++ch) {
@@ -131,6 +134,11 @@ hipError_t acquire_device_dict(int device, const mpc::Dictionary& dict, std::sha
         std::memcpy(det.data() + ch * det_rows * mpc::kTileN, dict.detail[ch].data(), det_rows * mpc::kTileN * sizeof(double));
     e = upload(&d->d_base, base.data(), base.size());
     if (e == hipSuccess) e = upload(&d->d_detail, det.data(), det.size());
+    {
+        const std::vector<float> base32(base.begin(), base.end()), det32(det.begin(), det.end());      // round to nearest
+        if (e == hipSuccess) e = upload(&d->d_base32, base32.data(), base32.size());
+        if (e == hipSuccess) e = upload(&d->d_detail32, det32.data(), det32.size());
+    }
     if (e == hipSuccess) e = upload(&d->d_rows, dict.block_rows.data(), dict.block_rows.size());
     if (e == hipSuccess) e = upload(&d->d_rowoff, dict.block_row_off.data(), dict.block_row_off.size());
     // split-bfloat16 filter copies: base rows as 32 tiles of 16 rows, every detail block as 4; both k orders
@@ -184,6 +192,7 @@ hipError_t acquire_device_dict(int device, const mpc::Dictionary& dict, std::sha
 struct mpc_context {
     int K = 0, block_size = 0, device = -1;
     double bpp = 0.0;
+    bool fast = false;                // the `...Fast` (float) flavour of the tile path (mpc_context_set_fast)
     mpc::Dictionary dict;
     std::vector<double> quant;        // [3*K]
     std::shared_ptr<DeviceDict> dd;   // owns the dictionary's device residents; the pointers below alias it
@@ -280,6 +289,8 @@ mpc::DictDevice dict_device(const mpc_context* c) {
     d.num_base = c->dict.num_base;
     d.base_rows_padded = c->base_rows_padded;
     d.detail = c->d_detail;
+    d.base32 = c->dd ? c->dd->d_base32 : nullptr;
+    d.detail32 = c->dd ? c->dd->d_detail32 : nullptr;
     d.detail_rows = c->dict.total_detail_rows();
     d.block_rows = c->d_rows;
     d.block0_rows = c->dict.block_rows.empty() ? 0 : c->dict.block_rows[0];
@@ -375,9 +386,12 @@ mpc_status run_persistent(mpc_context* c, const mpc::FrameInput& in, const mpc::
     const long long n_sel = d.num_base + d.detail_rows, stride = static_cast<long long>(d.num_base) * 64;
     mpc::PursuitArgs a{};
     a.base = d.d_base;
+    a.base32 = d.d_base32;
+    a.fast = c->fast ? 1 : 0;
     a.base_tiles = d.d_base_t1;
     for (int ch = 0; ch < 3; ++ch) {
         a.detail[ch] = d.d_detail + static_cast<size_t>(ch) * d.detail_rows * mpc::kTileN;
+        a.detail32[ch] = d.d_detail32 + static_cast<size_t>(ch) * d.detail_rows * mpc::kTileN;
         a.block_tiles[ch] = d.d_detail_t1 + static_cast<size_t>(ch) * d.num_base * mpc::kBlockFilterTiles * mpc::kFilterTileHalves;
         a.gram[ch] = d.d_gram + static_cast<size_t>(ch) * n_sel * stride;
         a.pair_p[ch] = d.pair_p[ch];
@@ -450,6 +464,7 @@ mpc_status run_pursuit(mpc_context* c, const mpc::FrameInput& in, const mpc::Out
     // MPC_PATH=steps: the step-synchronous kernels of mp_kernels.hip (with MPC_FILTER=0: their exhaustive double sweeps, the
     // product's own cross-check); default: the persistent kernel
     if (!steps_path()) return run_persistent(c, in, out, d_quant, total_tc, stream);
+    if (c->fast) return fail(MPC_ERR_ARGUMENT, "the float flavour runs on the persistent kernel only (unset MPC_PATH / MPC_FILTER)");
     mpc_status st = ensure_workspace(c, total_tc);
     if (st != MPC_OK) return st;
     const mpc::DictDevice dict = dict_device(c);
@@ -593,6 +608,14 @@ int mpc_context_num_base(const mpc_context* c) { return c ? c->dict.num_base : 0
 int mpc_context_detail_rows(const mpc_context* c) { return c ? c->dict.total_detail_rows() : 0; }
 int mpc_context_device(const mpc_context* c) { return c ? c->device : -1; }
 int mpc_context_max_waves(const mpc_context* c) { return c ? c->max_waves : 0; }
+
+mpc_status mpc_context_set_fast(mpc_context* c, int on) {
+    if (!c) return fail(MPC_ERR_ARGUMENT, "null context");
+    std::lock_guard<std::recursive_mutex> one_host_call(c->host_calls);
+    c->fast = on != 0;
+    return MPC_OK;
+}
+int mpc_context_is_fast(const mpc_context* c) { return c && c->fast ? 1 : 0; }
 
 mpc_status mpc_context_get_quant(const mpc_context* c, double* quant) {
     if (!c || !quant) return fail(MPC_ERR_ARGUMENT, "null argument");
@@ -1720,6 +1743,7 @@ static mpc_status decode_tiles_on_device(mpc_context* c, const uint16_t* d_count
     p.tiles_y = (height + 7) / 8;
     p.rgb = d_rgb;
     p.error_flag = c->d_flag;
+    p.fast = c->fast ? 1 : 0;
     const int err = mpc::launch_decode(dict_device(c), p, stream);
     if (err != 0) return fail(MPC_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(err)));
     return MPC_OK;

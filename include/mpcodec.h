@@ -79,6 +79,16 @@ int mpc_context_detail_rows(const mpc_context* ctx);       /* 31622 for 8x8, per
 int mpc_context_device(const mpc_context* ctx);
 int mpc_context_max_waves(const mpc_context* ctx);          /* resident waves of the encode kernel on the device */
 
+/* The `...Fast` flavour of the tile path (CompressionLib/inc/MatchingPursuit.h:23,26, CompressedImage.h:67-76 -- what
+ * Compression.cpp itself calls): residual, projections, quantisation, update and reconstruction in float on the dictionary
+ * rounded to float.  on != 0 switches every encode / decode entry point of this context to it; the container format and the
+ * entropy stage are the double path's.  PARITY UNPINNED: the reference's float results come from Eigen (absent from the
+ * tree) on a dictionary built by Eigen's float eigensolver; what runs here is the reference's statements read literally in
+ * float (sequential sums, products and sums rounded separately), bit-identical to oracle/mpo_fast.c and equivalent to the
+ * double path in PSNR and size, not in bytes. */
+mpc_status mpc_context_set_fast(mpc_context* ctx, int on);
+int mpc_context_is_fast(const mpc_context* ctx);
+
 /* quant[3*K]: Y then U then V */
 mpc_status mpc_context_get_quant(const mpc_context* ctx, double* quant);
 mpc_status mpc_context_set_quant(mpc_context* ctx, const double* quant);

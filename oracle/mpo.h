@@ -107,6 +107,23 @@ void mpo_encode_tiles(const mpo_ctx *c, const uint8_t *rgb, int W, int H,
                       uint16_t *counts, uint16_t *delta, uint16_t *coef,
                       double *energy, uint32_t *swept);
 
+/* ---- the `...Fast` (float) flavour: a DEFINITION of the float mode, parity unpinned (mpo_fast.c) ---- */
+typedef struct mpo_fast mpo_fast;
+mpo_fast *mpo_fast_create(const mpo_ctx *c);         /* float copies of c's dictionary; c must outlive it */
+void mpo_fast_destroy(mpo_fast *f);
+/* CalcMPDynamicFast MatchingPursuit.cpp:76-107 */
+int mpo_calc_mp_fast(const mpo_fast *f, int ch, const float *quant, const float *in,
+                     uint16_t *delta_id, uint16_t *int_coeff, float *resid, uint32_t *swept);
+/* FromCoeffsDynamicFast MatchingPursuit.cpp:130-147 */
+void mpo_from_coeffs_fast(const mpo_fast *f, int ch, const float *quant, int count,
+                          const uint16_t *delta_id, const uint16_t *int_coeff, float *out);
+/* the tile loop of encodeImageFast CompressedImage.cpp:592-630; outputs as mpo_encode_tiles */
+void mpo_encode_tiles_fast(const mpo_fast *f, const uint8_t *rgb, int W, int H,
+                           const double *qY, const double *qU, const double *qV,
+                           int tx_begin, int tx_end,
+                           uint16_t *counts, uint16_t *delta, uint16_t *coef,
+                           double *energy, uint32_t *swept);
+
 /* ---- bit buffer (CompressionLib/src/BitBuffer.cpp) ---- */
 typedef struct {
     uint64_t *w; size_t cap;      /* words                                  */
@@ -182,6 +199,11 @@ uint8_t *mpo_encode_image(const mpo_ctx *c, const uint8_t *rgb, int W, int H,
                           size_t *nbytes);
 /* decodeImage :783-835; rgb_out = W*H*3 malloc'd; returns 0 ok */
 int mpo_decode_image(const uint8_t *bytes, size_t nbytes, uint8_t **rgb_out, int *W, int *H);
+
+/* encodeImageFast :578-633 / decodeImageFast :837-889 */
+uint8_t *mpo_encode_image_fast(const mpo_fast *f, const uint8_t *rgb, int W, int H,
+                               const double *qY, const double *qU, const double *qV, size_t *nbytes);
+int mpo_decode_image_fast(const uint8_t *bytes, size_t nbytes, uint8_t **rgb_out, int *W, int *H);
 
 /* calculatePSNR :343-357 */
 double mpo_psnr(const uint8_t *a, const uint8_t *b, int W, int H);

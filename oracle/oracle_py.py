@@ -78,6 +78,19 @@ def lib():
         L.mpo_encode_image.argtypes = [C.POINTER(Ctx), u8p, C.c_int, C.c_int, dp, dp, dp, C.POINTER(C.c_size_t)]
         L.mpo_decode_image.restype = C.c_int
         L.mpo_decode_image.argtypes = [u8p, C.c_size_t, C.POINTER(u8p), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        fp = C.POINTER(C.c_float)
+        L.mpo_fast_create.restype = C.c_void_p
+        L.mpo_fast_create.argtypes = [C.POINTER(Ctx)]
+        L.mpo_fast_destroy.argtypes = [C.c_void_p]
+        L.mpo_calc_mp_fast.restype = C.c_int
+        L.mpo_calc_mp_fast.argtypes = [C.c_void_p, C.c_int, fp, fp, u16p, u16p, fp, C.POINTER(C.c_uint32)]
+        L.mpo_from_coeffs_fast.argtypes = [C.c_void_p, C.c_int, fp, C.c_int, u16p, u16p, fp]
+        L.mpo_encode_tiles_fast.argtypes = [C.c_void_p, u8p, C.c_int, C.c_int, dp, dp, dp, C.c_int, C.c_int,
+                                            u16p, u16p, u16p, dp, C.POINTER(C.c_uint32)]
+        L.mpo_encode_image_fast.restype = C.POINTER(C.c_uint8)
+        L.mpo_encode_image_fast.argtypes = [C.c_void_p, u8p, C.c_int, C.c_int, dp, dp, dp, C.POINTER(C.c_size_t)]
+        L.mpo_decode_image_fast.restype = C.c_int
+        L.mpo_decode_image_fast.argtypes = [u8p, C.c_size_t, C.POINTER(u8p), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.mpo_read_compressed.restype = C.c_int
         L.mpo_read_compressed.argtypes = [u8p, C.c_size_t, C.POINTER(Streams)]
         L.mpo_write_compressed.restype = C.POINTER(C.c_uint8)
@@ -245,6 +258,78 @@ class OracleContext:
         out = bytes(C.string_at(p, n.value))
         _libc_free(p)
         return out
+
+
+class OracleFastContext:
+    """The `...Fast` (float) flavour over an OracleContext's dictionary: mpo_fast.c's definition of the float mode."""
+
+    def __init__(self, octx):
+        self.ctx = octx
+        self.L = octx.L
+        self.K, self.N = octx.K, octx.N
+        self.p = self.L.mpo_fast_create(octx.p)
+
+    def close(self):
+        if self.p:
+            self.L.mpo_fast_destroy(self.p)
+            self.p = None
+
+    def __del__(self):
+        self.close()
+
+    def calc_mp(self, ch, vec, quant=None):
+        fp = C.POINTER(C.c_float)
+        q = np.ascontiguousarray(self.ctx.quant[ch] if quant is None else quant, dtype=np.float32)
+        v = np.ascontiguousarray(vec, dtype=np.float32)
+        d = np.zeros(self.K, np.uint16)
+        k = np.zeros(self.K, np.uint16)
+        res = np.zeros(self.N, np.float32)
+        S = C.c_uint32(0)
+        cnt = self.L.mpo_calc_mp_fast(self.p, ch, q.ctypes.data_as(fp), v.ctypes.data_as(fp), _u16p(d), _u16p(k),
+                                      res.ctypes.data_as(fp), C.byref(S))
+        return cnt, d, k, res, S.value
+
+    def encode_tiles(self, rgb, quant=None, tx_begin=0, tx_end=None):
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        H, W = rgb.shape[:2]
+        q = np.ascontiguousarray(self.ctx.quant if quant is None else quant, dtype=np.float64)
+        bs = self.ctx.bs
+        tx, ty = (W + bs - 1) // bs, (H + bs - 1) // bs
+        tx_end = tx if tx_end is None else tx_end
+        T = tx * ty
+        counts = np.zeros((T, 3), np.uint16)
+        delta = np.zeros((T, 3, self.K), np.uint16)
+        coef = np.zeros((T, 3, self.K), np.uint16)
+        energy = np.zeros((T, 3), np.float64)
+        swept = np.zeros((T, 3), np.uint32)
+        self.L.mpo_encode_tiles_fast(self.p, _u8p(rgb), W, H, _dp(q[0]), _dp(q[1]), _dp(q[2]), tx_begin, tx_end,
+                                     _u16p(counts), _u16p(delta), _u16p(coef), _dp(energy),
+                                     swept.ctypes.data_as(C.POINTER(C.c_uint32)))
+        return counts, delta, coef, energy, swept
+
+    def encode_image(self, rgb, quant=None):
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        H, W = rgb.shape[:2]
+        q = np.ascontiguousarray(self.ctx.quant if quant is None else quant, dtype=np.float64)
+        n = C.c_size_t(0)
+        p = self.L.mpo_encode_image_fast(self.p, _u8p(rgb), W, H, _dp(q[0]), _dp(q[1]), _dp(q[2]), C.byref(n))
+        out = bytes(C.string_at(p, n.value))
+        _libc_free(p)
+        return out
+
+
+def decode_image_fast(data):
+    L = lib()
+    buf = np.frombuffer(data, np.uint8)
+    out = C.POINTER(C.c_uint8)()
+    W = C.c_int(0)
+    H = C.c_int(0)
+    rc = L.mpo_decode_image_fast(_u8p(buf), len(data), C.byref(out), C.byref(W), C.byref(H))
+    if rc != 0:
+        raise ValueError("invalid bitstream")
+    img = np.ctypeslib.as_array(out, shape=(H.value, W.value, 3)).copy()
+    _libc_free(out)
+    return img
 
 
 _libc = C.CDLL(None)

@@ -25,8 +25,9 @@ def _build():
     return EXE
 
 
-def _run(mode, W, H, seed, quality, out):
-    r = subprocess.run([_build(), mode, str(W), str(H), str(seed), quality, str(out)], capture_output=True, text=True, timeout=600)
+def _run(mode, W, H, seed, quality, out, env=None):
+    r = subprocess.run([_build(), mode, str(W), str(H), str(seed), quality, str(out)], capture_output=True, text=True, timeout=600,
+                       env={**os.environ, **(env or {})})
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     return r.stdout
 
@@ -55,10 +56,13 @@ def test_compression_cpp_call_sequence_emits_the_oracles_bytes(tmp_path, oracle,
     octx = oracle.OracleContext(K, 8, 0.0 if quality == "max" else float(quality))
     q = np.ones((3, K)) if quality == "max" else None
     want = bytes(octx.encode_image(rgb, quant=q))
-    for mode in ("c", "f"):                                   # double names, and the ...Fast names Compression.cpp itself calls
+    want_fast = bytes(oracle.OracleFastContext(octx).encode_image(rgb, quant=q))
+    # double names; the ...Fast names Compression.cpp itself calls (float flavour: oracle/mpo_fast.c; parity unpinned against the
+    # reference's Eigen results); the Fast names served from the double path on request
+    for mode, env, expect in (("c", None, want), ("f", None, want_fast), ("f", {"MPC_FAST_EXACT": "1"}, want)):
         out = tmp_path / f"{mode}.mn"
-        _run(mode, W, H, 4242, quality, out)
-        assert out.read_bytes() == want, mode
+        _run(mode, W, H, 4242, quality, out, env)
+        assert out.read_bytes() == expect, (mode, env)
 
 
 @pytest.mark.gpu
