@@ -125,3 +125,22 @@ def test_decode_mn_against_jpeg(oracle, mn_bytes):
     psnr = L.mpo_psnr(oracle._u8p(ref), oracle._u8p(img), 4928, 3264)
     # calculatePSNR's formula carries +10*log10(3): 43.84 here == 39.07 dB conventional
     assert 43.5 < psnr < 44.2
+
+
+def test_float_flavour_of_the_oracle_agrees_with_the_double_path(oracle):
+    """oracle/mpo_fast.c (the `...Fast` flavour, parity unpinned: a definition, see its header) against the pinned double
+    restatement: same container up to choices that differ within float rounding -- PSNR within 0.05 dB, size within 1 %, the
+    float decoder within one grey level of the double decoder on the same container."""
+    rgb = oracle.synth_frame(200, 136, 31337)
+    octx = oracle.OracleContext(32, 8, 3.5)
+    fast = oracle.OracleFastContext(octx)
+    exact_blob, fast_blob = octx.encode_image(rgb), fast.encode_image(rgb)
+    assert abs(len(fast_blob) - len(exact_blob)) <= 0.01 * len(exact_blob)
+    u8p = oracle.C.POINTER(oracle.C.c_uint8)
+    psnr = lambda img: oracle.lib().mpo_psnr(rgb.ctypes.data_as(u8p), np.ascontiguousarray(img).ctypes.data_as(u8p), 200, 136)   # noqa: E731
+    assert abs(psnr(oracle.decode_image(exact_blob)) - psnr(oracle.decode_image_fast(fast_blob))) < 0.05
+    a, b = oracle.decode_image(exact_blob).astype(int), oracle.decode_image_fast(exact_blob).astype(int)
+    assert np.abs(a - b).max() <= 1
+    # CalcMPDynamicFast on a vector whose projections are all zero: Eigen's maxCoeff selects row 0, the coefficient quantises to 0
+    cnt, d, k, res, S = fast.calc_mp(0, np.zeros(64))
+    assert cnt == 0 and S == 510
