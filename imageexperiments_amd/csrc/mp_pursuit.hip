@@ -33,7 +33,9 @@ namespace {
 
 constexpr int N = 64;
 constexpr int kGroups = 1;                       // column groups (16 tile-channels each) per wave
-constexpr int kWaves = 12;                       // waves per workgroup (three per SIMD)
+constexpr int kWavesDouble = 12;                 // waves per workgroup: three per SIMD (168 VGPRs each)
+constexpr int kWavesFloat = 12;                  // measured: 16 waves (128 VGPRs) spill 32 registers and run 9 % slower than 12
+constexpr int kWavesMax = 16;                    // the per-wave scratch is sized for either
 constexpr int kTilesLds = kBaseFilterTiles + kBlockFilterTiles;     // 36
 constexpr double W_R = 0.299, W_G = 0.587, W_B = 0.114;            // ImageHelper/inc/misc.h:7-11
 constexpr double U_SCALE = 0.436 / (1.0 - 0.114);
@@ -257,7 +259,7 @@ __device__ __forceinline__ void keep_better(T& v, int& i, int& sel, T ov, int oi
 // T = double: the reference's double path, bit for bit.  T = float: the `...Fast` flavour (MatchingPursuit.cpp:27-37,76-107):
 // residual, exact evaluation, quantisation and update in float on the dictionary rounded to float -- the same screen (its
 // bound covers the float chain's own rounding, 64 x 2^-24 of the same sum), the same survivors logic, the same order.
-template <class T>
+template <class T, int kWaves>
 __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(const PursuitArgs a)
 {
     constexpr bool kFast = std::is_same<T, float>::value;
@@ -481,6 +483,7 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
         };
         static_for<kGroups>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
+            if (__ballot(on0[g])) { COUNT(17, 1) COUNT(18, __popcll(__ballot(on0[g] && h == 0))) }
             if (on0[g]) pair_update(gc, 0, upd0[g], info0[g], pv0[g], gv0[g], E0[g]);
         });
 #pragma unroll 1
@@ -510,6 +513,7 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
             }
             static_for<kGroups>([&](auto gc) {
                 constexpr int g = decltype(gc)::value;
+                COUNT(17, 1) COUNT(18, __popcll(__ballot(on[g] && h == 0)))
                 if (on[g]) pair_update(gc, p, upd[g], info[g], pv[g], gv[g], E[g]);
             });
         }
@@ -523,6 +527,7 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
             const bool mine = tc[g].live && tc[g].fresh >= 0;
             unsigned long long pend = __ballot(mine && h == 0);
             if (!pend) return;
+            COUNT(19, __popcll(pend))
             unsigned fresh_info = 0;
             if (mine)
                 fresh_info = (tc[g].fresh < 4 ? tc[g].packed(tc[g].fresh) : my_meta[2 * ((long long)(g * 16 + slot) * kMaxPairs + tc[g].fresh)]) & 0xFFFFu;
@@ -1006,17 +1011,19 @@ int launch_gram(const double* base, const double* detail, const int32_t* block_r
     return (int)hipGetLastError();
 }
 
-size_t pursuit_scratch_floats(int workgroups) { return (size_t)workgroups * kWaves * kGroups * 16 * kMaxPairs * 64; }
-size_t pursuit_scratch_meta(int workgroups) { return (size_t)workgroups * kWaves * kGroups * 16 * kMaxPairs * 2; }
-size_t pursuit_scratch_bounds(int workgroups) { return (size_t)workgroups * kWaves * kGroups * 16 * kMaxPairs; }
-int pursuit_units_per_workgroup() { return kWaves * kGroups; }
+size_t pursuit_scratch_floats(int workgroups) { return (size_t)workgroups * kWavesMax * kGroups * 16 * kMaxPairs * 64; }
+size_t pursuit_scratch_meta(int workgroups) { return (size_t)workgroups * kWavesMax * kGroups * 16 * kMaxPairs * 2; }
+size_t pursuit_scratch_bounds(int workgroups) { return (size_t)workgroups * kWavesMax * kGroups * 16 * kMaxPairs; }
+int pursuit_units_per_workgroup() { return kWavesDouble * kGroups; }
 
 int launch_pursuit(const PursuitArgs& args, void* stream)
 {
     const int workgroups = args.wg[0] + args.wg[1] + args.wg[2];
     if (workgroups < 1) return (int)hipErrorInvalidValue;
-    if (args.fast) hipLaunchKernelGGL(mp_pursuit_kernel<float>, dim3((unsigned)workgroups), dim3(64 * kWaves), 0, static_cast<hipStream_t>(stream), args);
-    else hipLaunchKernelGGL(mp_pursuit_kernel<double>, dim3((unsigned)workgroups), dim3(64 * kWaves), 0, static_cast<hipStream_t>(stream), args);
+    if (args.fast)
+        hipLaunchKernelGGL((mp_pursuit_kernel<float, kWavesFloat>), dim3((unsigned)workgroups), dim3(64 * kWavesFloat), 0, static_cast<hipStream_t>(stream), args);
+    else
+        hipLaunchKernelGGL((mp_pursuit_kernel<double, kWavesDouble>), dim3((unsigned)workgroups), dim3(64 * kWavesDouble), 0, static_cast<hipStream_t>(stream), args);
     return (int)hipGetLastError();
 }
 

@@ -453,7 +453,8 @@ mpc_status run_persistent(mpc_context* c, const mpc::FrameInput& in, const mpc::
         std::fprintf(stderr, "[stamps wg%d x3] wave-steps %llu live-lanes/step %.1f pass2-groups %llu rounds %llu exhaustive %llu | cycles/wave-step:",
                      workgroups, hst[12], hst[12] ? (double)hst[16] / hst[12] / 4.0 : 0.0, hst[13], hst[14], hst[15]);
         for (int i = 0; i < 12; ++i) std::fprintf(stderr, " %d:%.0f", i, hst[12] ? (double)hst[i] / hst[12] : 0.0);
-        std::fprintf(stderr, " total %.0f\n", hst[12] ? (double)tot / hst[12] : 0.0);
+        std::fprintf(stderr, " total %.0f | pair rounds/step %.2f slots/round %.2f new pairs/step %.2f\n", hst[12] ? (double)tot / hst[12] : 0.0,
+                     hst[12] ? (double)hst[17] / hst[12] : 0.0, hst[17] ? (double)hst[18] / hst[17] : 0.0, hst[12] ? (double)hst[19] / hst[12] : 0.0);
     }
 #endif
     return MPC_OK;
