@@ -43,6 +43,13 @@ constexpr double V_SCALE = 0.615 / (1.0 - 0.299);
 constexpr float kSlack = 0x1p-13f;               // E = kSlack |r~| + kAbs bounds the split-bf16 MFMA error (mp_kernels.hip)
 constexpr float kAbs = 0x1p-100f;
 constexpr float kHuge = 1.0e30f;                 // beyond this the f32 side may overflow: the tile-channel is evaluated exhaustively
+#ifndef MPC_REFILL_AT
+#define MPC_REFILL_AT 16
+#endif
+// Finished slots of a wave are refilled from the queue once this many are free.  Measured (MI355X, 16 Mpixel frames): 1, 2, 4, 8
+// and 16 all within 3 % of each other, 16 the best on the natural frame (2.57 ms vs 2.66 at 4) -- filling the slots early keeps
+// 14+ of 16 busy instead of 11.6, but slots at different steps make every wave-step pay for its oldest slot's pair list.
+constexpr int kRefillAt = MPC_REFILL_AT;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
@@ -200,6 +207,8 @@ struct TileChannel {
     bool has0 = false, live = false;
     double coeff = 0.0;          // pending residual update (0 = none): r -= coeff * row
     int sel_g = 0;               // Gram row of the chosen atom (base row, or 510 + detail row)
+    int step = 0;                // MP step this tile-channel is at (slots of a wave are refilled one by one: steps differ)
+    int t = 0;                   // its index in the channel's list of tile-channels
     __device__ __forceinline__ unsigned packed(int p) const { return ((p < 2 ? pk0 : pk1) >> (16 * (p & 1))) & 0xFFFFu; }
 };
 
@@ -271,6 +280,7 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
     __shared__ uint4 s_tiles[kTilesLds * 256];                      // [tile][operand q][lane], 4 KiB per tile
     __shared__ int s_rows[512], s_rowoff[512];                      // block_rows / block_row_off
     __shared__ unsigned s_touch[64 * kWaves];                       // landing zone of the cache-touch loads (never read)
+    __shared__ double s_quant[kMaxDeviceK];                         // the channel's quantisers (steps differ per lane)
     // this workgroup's channel and its index among that channel's workgroups
     const int ch = (int)blockIdx.x < a.wg[0] ? 0 : ((int)blockIdx.x < a.wg[0] + a.wg[1] ? 1 : 2);
     const int wg_local = (int)blockIdx.x - (ch == 0 ? 0 : (ch == 1 ? a.wg[0] : a.wg[0] + a.wg[1]));
@@ -290,6 +300,7 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
             s_rows[i] = i < a.num_base ? a.block_rows[i] : 0;
             s_rowoff[i] = i < a.num_base ? a.block_row_off[i] : 0;
         }
+        if (threadIdx.x < kMaxDeviceK) s_quant[threadIdx.x] = (int)threadIdx.x < a.K ? quant[threadIdx.x] : 1.0;
     }
     __syncthreads();
 
@@ -304,11 +315,15 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
     const int K = a.K;
 
     unsigned n_mfma = 0, n_steps = 0;                               // executed MFMA instructions / tile-channel-steps of this wave
-    int unit[kGroups], step[kGroups];
+    int unit[kGroups];                                              // >= 0: a slot of the group is live
     T r[kGroups][16];
     TileChannel tc[kGroups];
 #pragma unroll
-    for (int g = 0; g < kGroups; ++g) { unit[g] = -1; step[g] = 0; }
+    for (int g = 0; g < kGroups; ++g) {
+        unit[g] = -1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) r[g][i] = 0;
+    }
     bool queue_empty = false;
 
     auto tile_mfma = [&](const uint4 (&av)[4], const bf16x8 (&hi)[2], const bf16x8 (&lo)[2]) {
@@ -324,34 +339,41 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
         }
         return acc;
     };
-    // record index of this lane's tile-channel in unit u: counts[rec], choices[rec * K + step]
-    auto rec_of = [&](int u) { const long long t = (long long)u * 16 + slot; return a.vec_in ? t : t * 3 + ch; };
+    // record index of tile-channel t of this channel: counts[rec], choices[rec * K + step]
+    auto rec_of = [&](int t) { return a.vec_in ? (long long)t : (long long)t * 3 + ch; };
     auto lds_tile = [&](uint4 (&dst)[4], int t) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) dst[q] = s_tiles[t * 256 + q * 64 + lane];
     };
 
     for (;;) {
-        // ---- (1) refill empty groups from the queue ---------------------------------------------------------------
+        // ---- (1) refill: slots whose tile-channel has ended take the next tile-channels from the queue, kRefillAt or more at
+        //      a time (one atomic per refill; a wave whose slots are all free refills at once)
         static_for<kGroups>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
-            if (unit[g] >= 0 || queue_empty) return;
-            int u = 0;
-            if (lane == 0) u = (int)atomicAdd(queue, 1u);
-            u = __builtin_amdgcn_readfirstlane(u);
-            if (u >= a.n_units) { queue_empty = true; return; }
-            unit[g] = u;
-            step[g] = 0;
-            const long long t = (long long)u * 16 + slot;
+            if (queue_empty) return;
+            const unsigned free_slots = (unsigned)(__ballot(!tc[g].live) & 0xFFFFull);      // lane row 0 speaks for its slot
+            const int n_free = __popc(free_slots);
+            if (!(n_free >= kRefillAt || (unit[g] < 0 && n_free > 0))) return;
+            int first = 0;
+            if (lane == 0) first = (int)atomicAdd(queue, (unsigned)n_free);
+            first = __builtin_amdgcn_readfirstlane(first);
+            if ((long long)first + n_free >= a.n_tc) queue_empty = true;
+            const long long t = (long long)first + __popc(free_slots & ((1u << slot) - 1u));
+            const bool take = !tc[g].live && t < a.n_tc;
+            if (!__ballot(take)) return;
+            unit[g] = 0;
             TileChannel s;
-            s.live = t < a.n_tc;
+            s.live = true;
+            s.t = (int)t;
             s.next_off = a.num_base;
-            const long long ts = s.live ? t : 0;                    // loads below are unconditional: always a valid address
+            const long long ts = take ? t : 0;                      // loads below are unconditional: always a valid address
+            T fresh_r[16];
             if (a.vec_in) {
                 double in[16];
                 load16(in, a.vec_in + ts * N + pix0);
 #pragma unroll
-                for (int i = 0; i < 16; ++i) r[g][i] = (T)in[i];
+                for (int i = 0; i < 16; ++i) fresh_r[i] = (T)in[i];
             } else {
                 const int tiles_per_frame = a.tiles_x * a.tile_rows;
                 const int frame = (int)(ts / tiles_per_frame);
@@ -372,13 +394,14 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
                     const double red = (double)px[i][0], green = (double)px[i][1], blue = (double)px[i][2];
                     const double Y = (W_R * red + W_G * green + W_B * blue);            // misc.cpp:12-21, same expression order
                     const double v = ch == 0 ? Y : (ch == 1 ? (U_SCALE * (blue - Y)) : (V_SCALE * (red - Y)));
-                    r[g][i] = (T)((x < a.width && y < a.height) ? v : 0.0);            // zero fill (CompressedImage.cpp:548-552); Fast: static_cast<float> (:601-605)
+                    fresh_r[i] = (T)((x < a.width && y < a.height) ? v : 0.0);         // zero fill (CompressedImage.cpp:548-552); Fast: static_cast<float> (:601-605)
                 }
             }
-            if (!s.live)
+            if (take) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) r[g][i] = 0;
-            tc[g] = s;
+                for (int i = 0; i < 16; ++i) r[g][i] = fresh_r[i];
+                tc[g] = s;
+            }
         });
         bool any_unit = false;
 #pragma unroll
@@ -849,22 +872,22 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
             int count = 0;
             unsigned record = 0;
             if (best_idx[g] < 0) {
-                ended[g] = true; count = step[g];
+                ended[g] = true; count = s.step;
             } else {
                 const int id = best_idx[g];
-                const unsigned delta = step[g] > 0 ? (((unsigned)(id - s.prev_id) << 1) ^ (unsigned)((id - s.prev_id) >> 31)) : (unsigned)id;
+                const unsigned delta = s.step > 0 ? (((unsigned)(id - s.prev_id) << 1) ^ (unsigned)((id - s.prev_id) >> 31)) : (unsigned)id;
                 s.prev_id = id;
-                const T qstep = (T)quant[step[g]];              // Fast: Eigen::VectorXf quantization
+                const T qstep = (T)s_quant[s.step];             // Fast: Eigen::VectorXf quantization
                 const T ratio = best_val[g] / qstep;
                 const int q = kFast ? (int)__builtin_roundf((float)ratio) : (int)__builtin_round((double)ratio);
                 const unsigned zz = ((unsigned)q << 1) ^ (unsigned)(q >> 31);
                 record = (delta & 0xFFFFu) | ((zz & 0xFFFFu) << 16);
                 if (q == 0) {
-                    ended[g] = true; count = step[g];
+                    ended[g] = true; count = s.step;
                 } else {
                     s.coeff = (double)(qstep * (T)q);              // a float product is exact in the double that carries it
                     s.sel_g = best_sel[g];
-                    if (step[g] + 1 == K) { ended[g] = true; count = K; }
+                    if (s.step + 1 == K) { ended[g] = true; count = K; }
                     else if (id < a.num_base) {                     // unlock DetailBasis[id]; a repeat is indexed, not swept again
                         const int rows = s_rows[id];
                         bool repeat = id == 0 && s.has0;
@@ -889,8 +912,8 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
                 }
             }
             if (h == 0) {
-                const long long rec = rec_of(unit[g]);
-                a.out.choices[rec * K + step[g]] = record;
+                const long long rec = rec_of(s.t);
+                a.out.choices[rec * K + s.step] = record;
                 if (ended[g]) {
                     a.out.counts[rec] = (uint16_t)count;
                     if (a.out.swept) a.out.swept[rec] = s.swept;
@@ -919,7 +942,7 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
 #pragma unroll
                 for (int i = 0; i < 16; ++i) sq[i] = r[g][i] * r[g][i];
                 const T e2 = chain_sum(sq, h);
-                if (s.live && ended[g] && h == 0) a.out.energy[rec_of(unit[g])] = (double)e2;
+                if (s.live && ended[g] && h == 0) a.out.energy[rec_of(s.t)] = (double)e2;
             }
             if (upd && !ended[g] && h < 2) {
                 const int np = s.npairs < 4 ? s.npairs : 4;
@@ -939,7 +962,7 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
                 __builtin_amdgcn_global_load_lds(tiles + 4096, my_touch, 4, 0, 0);
             }
             if (ended[g]) s.live = false;
-            step[g] += 1;
+            s.step += 1;
             if (!__ballot(s.live)) unit[g] = -1;
         });
         STAMP(11)

@@ -1163,6 +1163,16 @@ mpc_status mpc_elias_fano_decode(const uint8_t* bytes, size_t nbytes, size_t n, 
 namespace {
 constexpr unsigned kTripleCap = 1u << 20;
 
+// MPC_ENTROPY_TRIPLES=n lowers the number of (symbol, count, first position) triples a frame may have before it takes the host
+// route (tests use it to exercise that route behind a completed phase 1)
+unsigned triple_limit() {
+    static const unsigned limit = [] {
+        const int v = env_int("MPC_ENTROPY_TRIPLES", 0);
+        return v > 0 && static_cast<unsigned>(v) < kTripleCap ? static_cast<unsigned>(v) : kTripleCap;
+    }();
+    return limit;
+}
+
 bool host_entropy_forced() {
     static const bool forced = env_int("MPC_HOST_ENTROPY", 0) != 0;
     return forced;
@@ -1283,7 +1293,7 @@ EntropyResult finish_entropy_on_device(const EntropyBuffers& b, int device_block
     auto tell = [&] { if (!told && enqueued) enqueued(); told = true; };
     struct TellOnExit { decltype(tell)& f; ~TellOnExit() { f(); } } tell_on_exit{tell};
     const int S = a.n_streams;
-    if (b.h_totals[3] != 0 || b.h_totals[2] > kTripleCap) return EntropyResult::kNeedsHost;
+    if (b.h_totals[3] != 0 || b.h_totals[2] > triple_limit()) return EntropyResult::kNeedsHost;
     stamp(0);
     std::vector<mpc::StreamPlan> plans(static_cast<size_t>(S));
     mpc::parallel_jobs(S, [&](int j) {

@@ -8,6 +8,7 @@
 #include "../../imageexperiments_amd/csrc/host_stats.cpp"
 
 #include <cstdio>
+#include <cstring>
 #include <fstream>
 #include <random>
 
@@ -134,6 +135,34 @@ int main(int argc, char** argv) {
             const std::vector<uint8_t> blob = random_container(rng, shape.first, shape.second, K);
             fuzz(blob, rng, 60, 120);
         }
+    {   // the planned route of the entropy stage (plan_stream / or_bits: the host's half of the device-side stage) against the direct one
+        for (int rep = 0; rep < 12; ++rep) {
+            const int K = 1 + static_cast<int>(rng() % 4), W = 64, H = 40;
+            const size_t tiles = static_cast<size_t>(W / 8) * (H / 8);
+            std::vector<uint16_t> counts(3 * tiles);
+            for (uint16_t& c : counts) c = static_cast<uint16_t>(rng() % (K + 1));
+            std::vector<unsigned long long> off(6 * static_cast<size_t>(K) + 1, 0);
+            std::vector<uint16_t> symbols;
+            for (int st = 0; st < 6 * K; ++st) {
+                const size_t n = rng() % 3 == 0 ? 0 : rng() % 70000;
+                const unsigned range = 1u << (rng() % 16);
+                uint16_t v = 0;
+                for (size_t i = 0; i < n; ++i) {
+                    if (rng() % 8 != 0 || i == 0) v = static_cast<uint16_t>(rng() % range);       // runs of equal symbols
+                    if (rng() % 5000 == 0) { symbols.insert(symbols.end(), 40000, v); i += 40000; }   // long enough to be cut at 0x8001
+                    symbols.push_back(v);
+                }
+                off[static_cast<size_t>(st) + 1] = symbols.size();
+            }
+            std::vector<double> q(3 * static_cast<size_t>(K), 8.0);
+            size_t n1 = 0, n2 = 0;
+            uint8_t* direct = mpc::encode_symbol_streams_malloc(W, H, K, 8, q.data(), counts.data(), symbols.data(), off.data(), &n1);
+            uint8_t* planned = mpc::encode_symbol_streams_by_plan_malloc(W, H, K, 8, q.data(), counts.data(), symbols.data(), off.data(), &n2);
+            CHECK(direct && planned && n1 == n2 && std::memcmp(direct, planned, n1) == 0);
+            std::free(direct);
+            std::free(planned);
+        }
+    }
     if (argc > 1) {                                                   // the reference's own bitstream
         std::ifstream f(argv[1], std::ios::binary);
         std::vector<uint8_t> mn((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
