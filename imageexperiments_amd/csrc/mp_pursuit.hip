@@ -178,6 +178,20 @@ struct TopKeys {
         k1 = __uint_as_float(k1b > key ? k1b : key);
     }
 };
+// The mask of a key lives in a VECTOR register: v_and_or_b32 may read one scalar operand only (the code, a loop counter), so a
+// scalar or literal mask would split every key into v_and + v_or -- one more VALU instruction per tracked value.
+__device__ __forceinline__ unsigned in_vgpr(unsigned x)
+{
+    unsigned v;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(x));
+    return v;
+}
+__device__ __forceinline__ unsigned in_sgpr(unsigned x)          // x is wave-uniform; keeps the compiler from folding it into a literal
+{
+    unsigned v;
+    asm volatile("s_mov_b32 %0, %1" : "=s"(v) : "s"(x));
+    return v;
+}
 constexpr unsigned kKeepRow = 0x7FFFFF80u;        // |value| with 7 code bits: tile (5) and row within the lane's four (2)
 constexpr unsigned kKeepPair = 0x7FFFFE00u;      // |value| with 9 code bits: pair (5), tile (2), row (2)
 
@@ -314,6 +328,7 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
     unsigned* const my_touch = s_touch + 64 * wave;
     const int K = a.K;
 
+    const unsigned keep_row_mask = in_vgpr(kKeepRow), keep_pair_mask = in_vgpr(kKeepPair);
     unsigned n_mfma = 0, n_steps = 0;                               // executed MFMA instructions / tile-channel-steps of this wave
     int unit[kGroups];                                              // >= 0: a slot of the group is live
     T r[kGroups][16];
@@ -463,7 +478,8 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
         bool oddp[kGroups];
 #pragma unroll
         for (int g = 0; g < kGroups; ++g) { lbmax[g] = -3.0e38f; oddp[g] = false; }
-        auto pair_update = [&](auto gc, int p, bool upd, unsigned info, float4 (&pv)[4], const float4 (&gv)[4], float E) {
+        // same_p: p is the same in every lane (a loop counter): every key's code then sits in a scalar register of its own
+        auto pair_update = [&](auto gc, auto same_p, int p, bool upd, unsigned info, float4 (&pv)[4], const float4 (&gv)[4], float E) {
             constexpr int g = decltype(gc)::value;
             const long long pi = (long long)(g * 16 + slot) * kMaxPairs + p;
             const int rows = (int)((info >> 9) & 127u);
@@ -487,7 +503,7 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
             // rows 62 and 63 of a block can be pads (blocks have 62 or 63 rows): lane row h = 3, tile 3, v = 2, 3.  Their P and G
             // are exactly 0; their upper bound must be 0 too (not E), or a pad could pass for a survivor.
             const bool pad2 = h == 3 && rows < 63, pad3 = h == 3 && rows < 64;
-            const unsigned keepp = __builtin_amdgcn_readfirstlane((int)(kKeepPair | (lane >> 8)));
+            const unsigned keepp = keep_pair_mask;
             float biggest = 0.0f;                                   // of this pair's |P|: its lower bound is biggest - E
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -498,7 +514,8 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
                     float ub = m + E;
                     if (t == 3 && v == 2) ub = pad2 ? 0.0f : ub;
                     if (t == 3 && v == 3) ub = pad3 ? 0.0f : ub;
-                    tp[g].see(__float_as_uint(ub), keepp, (unsigned)((p << 4) | (t << 2) | v));
+                    const unsigned code = (unsigned)((p << 4) | (t << 2) | v);
+                    tp[g].see(__float_as_uint(ub), keepp, decltype(same_p)::value ? in_sgpr((unsigned)__builtin_amdgcn_readfirstlane((int)code)) : code);
                     biggest = __builtin_amdgcn_fmed3f(biggest, m, __builtin_inff());
                 }
             }
@@ -507,7 +524,7 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
         static_for<kGroups>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
             if (__ballot(on0[g])) { COUNT(17, 1) COUNT(18, __popcll(__ballot(on0[g] && h == 0))) }
-            if (on0[g]) pair_update(gc, 0, upd0[g], info0[g], pv0[g], gv0[g], E0[g]);
+            if (on0[g]) pair_update(gc, std::true_type{}, 0, upd0[g], info0[g], pv0[g], gv0[g], E0[g]);
         });
 #pragma unroll 1
         for (int p = 1;; ++p) {                                     // further pairs: both groups' loads of a round issued together
@@ -537,7 +554,7 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
             static_for<kGroups>([&](auto gc) {
                 constexpr int g = decltype(gc)::value;
                 COUNT(17, 1) COUNT(18, __popcll(__ballot(on[g] && h == 0)))
-                if (on[g]) pair_update(gc, p, upd[g], info[g], pv[g], gv[g], E[g]);
+                if (on[g]) pair_update(gc, std::true_type{}, p, upd[g], info[g], pv[g], gv[g], E[g]);
             });
         }
         STAMP(2)
@@ -583,7 +600,7 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
                 for (int t = 0; t < 4; ++t) dst[4 * t] = pnew[t];
                 if (h == 0) my_e[(g * 16 + slot) * kMaxPairs + tc[g].fresh] = Eb[g];
                 const float4 none[4] = {};
-                pair_update(gc, tc[g].fresh, false, fresh_info, pnew, none, Eb[g]);
+                pair_update(gc, std::false_type{}, tc[g].fresh, false, fresh_info, pnew, none, Eb[g]);
             }
         });
         STAMP(3)
@@ -600,11 +617,11 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
         {
             uint4 ta[4], tbuf[4];
             f32x4 acc[kGroups], prev[kGroups];
-            const unsigned keep = __builtin_amdgcn_readfirstlane((int)(kKeepRow | (lane >> 8)));      // in a register: v_and_or_b32
+            const unsigned keep = keep_row_mask;
             auto track = [&](TopKeys (&trk)[kGroups], const f32x4 (&val)[kGroups], unsigned code0) {
                 unsigned code[4];
 #pragma unroll
-                for (int v = 0; v < 4; ++v) code[v] = code0 + v;
+                for (int v = 0; v < 4; ++v) code[v] = (unsigned)__builtin_amdgcn_readfirstlane((int)(code0 + v));    // each in a scalar register
 #pragma unroll
                 for (int g = 0; g < kGroups; ++g)
 #pragma unroll
