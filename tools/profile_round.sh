@@ -24,6 +24,11 @@ for w in raise 1080p 8k; do
   cp $P/${tag}_pmc_$w.json $R/profiles/${tag}_pmc_$w.json      # bench.py (below) reads roofline.traffic from profiles/
   echo "pmc $w done"
 done
+# the whole pipeline of bench.py's value (pursuit, stream assembly, entropy kernels, the container's copy) in one trace
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_stats_pipeline -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu > $O/${tag}_stats_pipeline.log 2>&1
+cp $O/${tag}_stats_pipeline/*/*kernel_stats.csv $P/${tag}_kernel_stats_pipeline_raise.csv
+python3 $R/tools/pipeline_timeline.py $O/${tag}_stats_pipeline/*/*kernel_trace.csv $P/${tag}_timeline_pipeline_raise.txt
+echo "pipeline stats done"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_VALU_MFMA_BUSY_CYCLES \
   --output-format csv -d $O/${tag}_pmc_sq -- python3 $R/tools/quick_bench.py raise 2 > $O/${tag}_pmc_sq.log 2>&1
 python3 $R/tools/pmc_sq_summary.py $O/${tag}_pmc_sq/*/*counter_collection.csv $P/${tag}_pmc_sq_raise.json
