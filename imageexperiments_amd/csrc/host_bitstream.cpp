@@ -104,6 +104,13 @@ uint64_t BitReader::get(int width) {
     if (width <= 0) return 0;
     const size_t left = nbits_ - pos_;
     if (static_cast<size_t>(width) > left) width = static_cast<int>(left);
+    if (width <= 56 && (pos_ >> 3) + 8 <= ((nbits_ + 7) >> 3)) {      // one unaligned 64-bit load covers offset + width
+        uint64_t w;
+        std::memcpy(&w, p_ + (pos_ >> 3), 8);
+        w = __builtin_bswap64(w) << (pos_ & 7);
+        pos_ += static_cast<size_t>(width);
+        return width ? w >> (64 - width) : 0;
+    }
     uint64_t v = 0;
     int need = width;
     while (need > 0) {
@@ -122,6 +129,11 @@ uint32_t BitReader::peek32() const {
     const size_t byte = pos_ >> 3;
     const int off = static_cast<int>(pos_ & 7);
     const size_t nbytes = (nbits_ + 7) >> 3;
+    if (byte + 8 <= nbytes) {
+        uint64_t w;
+        std::memcpy(&w, p_ + byte, 8);
+        return static_cast<uint32_t>((__builtin_bswap64(w) << off) >> 32);
+    }
     uint64_t window = 0;                                        // 5 bytes cover 32 bits at any bit offset
     if (byte + 5 <= nbytes) {
         window = (static_cast<uint64_t>(p_[byte]) << 32) | (static_cast<uint64_t>(p_[byte + 1]) << 24) |
@@ -161,9 +173,17 @@ void golomb_write(uint32_t value, uint32_t m, BitWriter& out) {
 
 uint32_t golomb_read(uint32_t m, BitReader& in) {
     uint32_t q = 0;
-    while (in.get(1) != 0) {
-        ++q;
-        if (in.remaining() == 0) break;
+    // the unary part, 32 bits at a time while they are all ones (same result as reading bit by bit: past the end reads as 0)
+    for (;;) {
+        const size_t left = in.remaining();
+        if (left == 0) break;
+        const uint32_t ones = static_cast<uint32_t>(__builtin_clz(~in.peek32() | 1u));      // leading ones, 31 at most counted here
+        if (ones >= 31 && left > 31) { q += 31; in.skip(31); continue; }
+        const uint32_t take = static_cast<uint32_t>(std::min<size_t>(ones, left));
+        q += take;
+        in.skip(take);
+        if (take < left) in.skip(1);                            // the terminating zero
+        break;
     }
     const uint32_t b = bit_width(m);
     const uint32_t limit = (1u << (b + 1)) - m;
@@ -784,7 +804,10 @@ void or_bits(uint8_t* dst, size_t bit_offset, const BitWriter& piece) {
 }
 
 bool read_huffman_or_golomb(BitReader& in, size_t length, std::vector<uint16_t>& out) {
-    if (in.get(1) == 0) return huffman_decode(in, out);
+    if (in.get(1) == 0) {
+        out.reserve(out.size() + std::min(length, in.remaining()));      // every code takes at least one bit
+        return huffman_decode(in, out);
+    }
     const uint32_t m = static_cast<uint32_t>(in.get(16));
     if (m == 0) return false;
     if (length > in.remaining()) return false;                  // every Golomb code takes at least one bit: a lying header
