@@ -204,11 +204,8 @@ def main():
     else:
         striped = sharding.StripedEncoder(ctx, W, H, frames, world, rank, args.backend)
 
-        def run(n):
-            out = []
-            for _ in range(n):
-                out.append(striped.step(d_rgb, stream))
-            return out
+        def run(n):                                          # n steps, software-pipelined on the rank's stream
+            return striped.run(d_rgb, stream, n, views=True)
 
     run(args.warmup)
     fence()

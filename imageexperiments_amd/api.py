@@ -113,6 +113,9 @@ def _bind_bitstream(L):
     L.mpc_encode_images_device.argtypes = [vp, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, _dp, C.POINTER(_u8p), C.POINTER(C.c_size_t)]
     L.mpc_records_to_container_device.argtypes = [vp, vp, vp, C.c_int, C.c_int, _dp, vp, C.POINTER(_u8p), C.POINTER(C.c_size_t)]
     L.mpc_encode_image_device.argtypes = [vp, vp, C.c_int, C.c_int, _dp, C.POINTER(_u8p), C.POINTER(C.c_size_t)]
+    L.mpc_container_job_begin.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int, _dp, vp]
+    L.mpc_container_job_tables.argtypes = [vp, C.c_int]
+    L.mpc_container_job_collect.argtypes = [vp, C.c_int, C.POINTER(_u8p), C.POINTER(C.c_size_t)]
     L.mpc_decode_tiles_device.argtypes = [vp, vp, vp, _dp, C.c_int, C.c_int, vp, vp]
     L.mpc_decode_image.argtypes = [vp, _u8p, C.c_size_t, C.POINTER(_u8p), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.mpc_patch_stats_create.argtypes = [vp, C.c_uint, C.POINTER(vp)]
@@ -565,6 +568,24 @@ class CompressionContext:
         _check(self.L.mpc_code_symbol_streams_device(self.h, width, height, qp, cp, symbols.ctypes.data_as(_u16p),
                                                      off.ctypes.data_as(C.POINTER(C.c_ulonglong)), C.byref(out), C.byref(n), C.byref(route)))
         return _take_bytes(self.L, out, n), route.value
+
+    def container_job_begin(self, slot, d_counts, d_choices, width, height, quant=None, stream=0):
+        """mpc_container_job_begin: stream assembly + entropy phase 1 of whole-frame records in device memory, enqueued only."""
+        qp = None
+        if quant is not None:
+            quant = np.ascontiguousarray(quant, np.float64).reshape(3, self.K)
+            qp = quant.ctypes.data_as(_dp)
+        _check(self.L.mpc_container_job_begin(self.h, slot, d_counts, d_choices, width, height, qp, stream or None))
+
+    def container_job_tables(self, slot):
+        """mpc_container_job_tables: wait for phase 1, build the code tables, enqueue phase 2 and the container's copy."""
+        _check(self.L.mpc_container_job_tables(self.h, slot))
+
+    def container_job_collect(self, slot, views=False):
+        """mpc_container_job_collect: wait for the copy -> container bytes (views=True: a uint8 array on the library's buffer)."""
+        out, n = _u8p(), C.c_size_t(0)
+        _check(self.L.mpc_container_job_collect(self.h, slot, C.byref(out), C.byref(n)))
+        return (_take_view if views else _take_bytes)(self.L, out, n)
 
     def calc_mp(self, channel, vectors, quant_k=None):
         """matching::CalcMPDynamic (MatchingPursuit.h:22) on the device for vectors[n,64].

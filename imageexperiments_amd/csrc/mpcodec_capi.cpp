@@ -234,6 +234,7 @@ struct mpc_context {
         int K = 0;
     };
     EntropySlot ent[kSeqSlots];
+    std::shared_ptr<void> jobs[kSeqSlots];           // ContainerJob (mpc_container_job_*): records on the device -> container, in steps
     // The pursuit of a call is cut into sub-batches that run on `pipes` internal streams, each with its own
     // workspace: the latency-bound bookkeeping kernels of one sub-batch (finish, update, bucket, fill) overlap
     // the machine-filling sweeps of the other.  Fork/join with events on the caller's stream: still no host
@@ -1280,29 +1281,33 @@ double trace_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - origin).count();
 }
 
-// The host's part and phase 2.  Phase 1 has completed (the caller waited for an event behind it): the statistics are in the
-// slot's host mirrors.  Everything is enqueued on `s` in order -- table import, the code kernels, the container's way to
-// the host -- and `enqueued()` (if any) is called once that is done (or once it is clear that nothing will be enqueued);
-// then this thread waits for `done` and patches the host's pieces in.  kNeedsHost: nothing written, take the host route.
-EntropyResult finish_entropy_on_device(const EntropyBuffers& b, int device_block_size, int width, int height, int K, const double* quant,
-                                       hipStream_t s, hipEvent_t done, const std::function<void()>& enqueued, uint8_t** blob,
-                                       size_t* nbytes, double* stamps = nullptr) {
+// The host's part and phase 2, in two steps.  Phase 1 has completed (the caller waited for an event behind it): the
+// statistics are in the slot's host mirrors.
+//   entropy_tables   builds the code tables and enqueues on `s`, in order: table import, the code kernels, the container's way
+//                    to the host, `done`.  kNeedsHost: nothing enqueued, take the host route.
+//   entropy_collect  waits for `done`, checks the device's bit counts against the tables', patches the host's pieces in.
+struct EntropyPending {
+    std::vector<mpc::StreamPlan> plans;
+    mpc::BitWriter head;
+    size_t total_bytes = 0;
+};
+
+EntropyResult entropy_tables(const EntropyBuffers& b, int device_block_size, int width, int height, int K, const double* quant,
+                             hipStream_t s, hipEvent_t done, EntropyPending* pending, double* stamps = nullptr) {
     const mpc::EntropyArgs& a = b.args;
     auto stamp = [&](int i) { if (stamps) stamps[i] = trace_ms(); };
-    bool told = false;
-    auto tell = [&] { if (!told && enqueued) enqueued(); told = true; };
-    struct TellOnExit { decltype(tell)& f; ~TellOnExit() { f(); } } tell_on_exit{tell};
     const int S = a.n_streams;
     if (b.h_totals[3] != 0 || b.h_totals[2] > triple_limit()) return EntropyResult::kNeedsHost;
     stamp(0);
-    std::vector<mpc::StreamPlan> plans(static_cast<size_t>(S));
+    std::vector<mpc::StreamPlan>& plans = pending->plans;
+    plans.assign(static_cast<size_t>(S), mpc::StreamPlan());
     mpc::parallel_jobs(S, [&](int j) {
         const mpc::EntStream& st = b.h_streams[j];
         mpc::plan_stream(j != 0, st.shorter != 0, st.rle_size, st.eff_n, st.largest, b.h_triples + 3 * static_cast<size_t>(st.triple_off),
                          st.distinct, plans[static_cast<size_t>(j)]);
     });
-    const mpc::BitWriter head = mpc::container_head(width, height, K, device_block_size, quant);
-    unsigned long long bit = head.bit_size(), raw_symbols = 0;
+    pending->head = mpc::container_head(width, height, K, device_block_size, quant);
+    unsigned long long bit = pending->head.bit_size(), raw_symbols = 0;
     size_t n_entries = 0;
     for (int j = 0; j < S; ++j) {
         const mpc::StreamPlan& p = plans[static_cast<size_t>(j)];
@@ -1318,6 +1323,7 @@ EntropyResult finish_entropy_on_device(const EntropyBuffers& b, int device_block
     }
     const size_t total_bytes = static_cast<size_t>((bit + 7) / 8), out_words = (total_bytes + 3) / 4;
     if (out_words * 4 > b.out_capacity || n_entries > kTripleCap) return EntropyResult::kNeedsHost;
+    pending->total_bytes = total_bytes;
     size_t at = 0;
     for (int j = 0; j < S; ++j) {
         const std::vector<uint32_t>& e = plans[static_cast<size_t>(j)].entries;
@@ -1334,24 +1340,40 @@ EntropyResult finish_entropy_on_device(const EntropyBuffers& b, int device_block
     const bool ok = hipMemsetAsync(b.d_out, 0, out_words * 4, s) == hipSuccess && mpc::launch_entropy_phase2(a2, raw_symbols, s) == 0 &&
                     hipMemcpyAsync(b.h_out, b.d_out, out_words * 4, hipMemcpyDeviceToHost, s) == hipSuccess &&
                     hipEventRecord(done, s) == hipSuccess;
-    tell();
-    if (!ok || hipEventSynchronize(done) != hipSuccess) return EntropyResult::kFailed;
-    stamp(2);                                                   // codes written, bytes on the host
+    return ok ? EntropyResult::kDone : EntropyResult::kFailed;
+}
+
+EntropyResult entropy_collect(const EntropyBuffers& b, const EntropyPending& pending, hipEvent_t done, uint8_t** blob, size_t* nbytes,
+                              double* stamps = nullptr) {
+    if (hipEventSynchronize(done) != hipSuccess) return EntropyResult::kFailed;
+    if (stamps) stamps[2] = trace_ms();                         // codes written, bytes on the host
+    const int S = b.args.n_streams;
     for (int j = 0; j < S; ++j)                                 // the device wrote exactly the bits the tables promise
-        if (b.h_streams[j].coded_bits != plans[static_cast<size_t>(j)].payload_bits) return EntropyResult::kFailed;
-    mpc::or_bits(b.h_out, 0, head);
+        if (b.h_streams[j].coded_bits != pending.plans[static_cast<size_t>(j)].payload_bits) return EntropyResult::kFailed;
+    mpc::or_bits(b.h_out, 0, pending.head);
     for (int j = 0; j < S; ++j) {
-        const mpc::StreamPlan& p = plans[static_cast<size_t>(j)];
+        const mpc::StreamPlan& p = pending.plans[static_cast<size_t>(j)];
         const unsigned long long payload = b.h_streams[j].bit_off;
         mpc::or_bits(b.h_out, static_cast<size_t>(payload - p.pre.bit_size()), p.pre);
         mpc::or_bits(b.h_out, static_cast<size_t>(payload + p.payload_bits), p.post);
     }
-    uint8_t* out = static_cast<uint8_t*>(std::malloc(total_bytes ? total_bytes : 1));
+    uint8_t* out = static_cast<uint8_t*>(std::malloc(pending.total_bytes ? pending.total_bytes : 1));
     if (!out) return EntropyResult::kFailed;
-    std::memcpy(out, b.h_out, total_bytes);
+    std::memcpy(out, b.h_out, pending.total_bytes);
     *blob = out;
-    *nbytes = total_bytes;
+    *nbytes = pending.total_bytes;
     return EntropyResult::kDone;
+}
+
+// both steps; `enqueued()` (if any) is called between them: once phase 2 is on the stream, or once it is clear that it will not be
+EntropyResult finish_entropy_on_device(const EntropyBuffers& b, int device_block_size, int width, int height, int K, const double* quant,
+                                       hipStream_t s, hipEvent_t done, const std::function<void()>& enqueued, uint8_t** blob,
+                                       size_t* nbytes, double* stamps = nullptr) {
+    EntropyPending pending;
+    const EntropyResult r = entropy_tables(b, device_block_size, width, height, K, quant, s, done, &pending, stamps);
+    if (enqueued) enqueued();
+    if (r != EntropyResult::kDone) return r;
+    return entropy_collect(b, pending, done, blob, nbytes, stamps);
 }
 }  // namespace
 
@@ -1576,24 +1598,49 @@ static mpc_status encode_sequence(mpc_context* c, const uint8_t* const* frames, 
     return st;
 }
 
-// The second half of encodeImage for records that are already on the device in whole-frame order (the owner of a frame in
-// the multi-GPU path, after the stripe exchange): stream assembly on `stream`, the live symbols to the host, entropy stage.
-mpc_status mpc_records_to_container_device(mpc_context* c, const uint16_t* d_counts, const mpc_basis_choice* d_choices, int width,
-                                           int height, const double* quant, void* stream, uint8_t** bytes, size_t* nbytes) {
-    return guarded([&]() -> mpc_status {
-    if (!c || !d_counts || !d_choices || !bytes || !nbytes) return fail(MPC_ERR_ARGUMENT, "null argument");
-    if (c->device < 0) return fail(MPC_ERR_NO_DEVICE, "context was created without a device");
-    if (width < 1 || height < 1) return fail(MPC_ERR_ARGUMENT, "bad geometry");
-    const size_t tiles = static_cast<size_t>((width + 7) / 8) * ((height + 7) / 8), n_tc = tiles * 3;
+// ---- records that are already on the device in whole-frame order -> container (the owner of a frame in the multi-GPU path,
+// after the stripe exchange), in three steps so that the caller can keep the device busy meanwhile:
+//   begin    stream assembly + entropy phase 1 enqueued on `stream`; nothing is waited for
+//   tables   waits for phase 1, builds the code tables, enqueues phase 2 and the container's copy on the same stream
+//   collect  waits for the copy; the container
+// One job per slot at a time.  mpc_records_to_container_device is the three in a row on slot 0.
+namespace {
+struct ContainerJob {
+    int stage = 0;                      // 0 idle, 1 begun, 2 tables done
+    int width = 0, height = 0;
+    std::vector<double> quant;
+    hipStream_t stream = nullptr;
+    void* dev = nullptr;                // stream assembly buffers of this slot (grow-only)
+    size_t dev_bytes = 0;
+    const uint16_t* d_counts = nullptr;
+    mpc::StreamArgs sa{};
+    EntropyBuffers eb;
+    bool device_entropy = false;
+    hipEvent_t phase1 = nullptr, done = nullptr;
+    EntropyPending pending;
+    uint8_t* blob = nullptr;            // the host route's result, ready at `tables`
+    size_t nblob = 0;
+    ~ContainerJob() {
+        if (dev) (void)hipFree(dev);
+        if (phase1) (void)hipEventDestroy(phase1);
+        if (done) (void)hipEventDestroy(done);
+        std::free(blob);
+    }
+};
+
+ContainerJob* job_of(mpc_context* c, int slot) {
+    if (!c->jobs[slot]) c->jobs[slot] = std::make_shared<ContainerJob>();
+    return static_cast<ContainerJob*>(c->jobs[slot].get());
+}
+
+// the host route: symbols across PCIe, entropy stage on the host (synchronous)
+mpc_status container_on_host(mpc_context* c, ContainerJob* j, uint8_t** bytes, size_t* nbytes) {
     const int K = c->K;
-    std::lock_guard<std::recursive_mutex> one_host_call(c->host_calls);
-    HIP_TRY(hipSetDevice(c->device));
+    const size_t tiles = static_cast<size_t>((j->width + 7) / 8) * ((j->height + 7) / 8), n_tc = tiles * 3;
     auto up = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
     const size_t counts_bytes = up(sizeof(uint16_t) * n_tc), off_bytes = up(sizeof(unsigned long long) * (6 * static_cast<size_t>(K) + 1));
     const size_t symbols_bytes = up(sizeof(uint16_t) * 2 * n_tc * K);
-    const size_t live_bytes = up(sizeof(unsigned) * mpc::stream_workspace_words(static_cast<long long>(tiles), K));
-    const size_t sizes_bytes = up(sizeof(unsigned) * 3 * K), dc_bytes = up(sizeof(uint16_t) * n_tc);
-    const size_t host_need = counts_bytes + off_bytes + symbols_bytes, dev_need = live_bytes + sizes_bytes + off_bytes + symbols_bytes + dc_bytes;
+    const size_t host_need = counts_bytes + off_bytes + symbols_bytes;
     if (host_need > c->host_stage_bytes) {
         if (c->host_stage) (void)hipHostFree(c->host_stage);
         c->host_stage = nullptr;
@@ -1602,18 +1649,58 @@ mpc_status mpc_records_to_container_device(mpc_context* c, const uint16_t* d_cou
         if (e != hipSuccess) return fail(MPC_ERR_ALLOC, "pinned staging of %zu bytes: %s", host_need, hipGetErrorString(e));
         c->host_stage_bytes = host_need;
     }
-    if (dev_need > c->stage_bytes) {
-        HIP_TRY(hipDeviceSynchronize());
-        if (c->stage) (void)hipFree(c->stage);
-        c->stage = nullptr;
-        c->stage_bytes = 0;
-        const hipError_t e = hipMalloc(&c->stage, dev_need);
-        if (e != hipSuccess) return fail(MPC_ERR_ALLOC, "device staging of %zu bytes: %s", dev_need, hipGetErrorString(e));
-        c->stage_bytes = dev_need;
-    }
-    char* dbase = static_cast<char*>(c->stage);
     char* hbase = static_cast<char*>(c->host_stage);
-    mpc::StreamArgs sa{};
+    uint16_t* counts = reinterpret_cast<uint16_t*>(hbase);
+    unsigned long long* off = reinterpret_cast<unsigned long long*>(hbase + counts_bytes);
+    uint16_t* symbols = reinterpret_cast<uint16_t*>(hbase + counts_bytes + off_bytes);
+    hipStream_t s = j->stream;
+    const size_t n_off = 6 * static_cast<size_t>(K) + 1;
+    HIP_TRY(hipMemcpyAsync(off, j->sa.stream_off, sizeof(unsigned long long) * n_off, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(counts, j->d_counts, sizeof(uint16_t) * n_tc, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const unsigned long long total = off[n_off - 1];
+    if (total > 2ULL * n_tc * static_cast<unsigned long long>(K)) return fail(MPC_ERR_HIP, "stream assembly returned an impossible size");
+    if (total) HIP_TRY(hipMemcpyAsync(symbols, j->sa.symbols, sizeof(uint16_t) * total, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    *bytes = mpc::encode_symbol_streams_malloc(j->width, j->height, K, c->block_size, j->quant.data(), counts, symbols, off, nbytes);
+    return *bytes ? MPC_OK : fail(MPC_ERR_ALLOC, "out of memory");
+}
+}  // namespace
+
+mpc_status mpc_container_job_begin(mpc_context* c, int slot, const uint16_t* d_counts, const mpc_basis_choice* d_choices, int width,
+                                   int height, const double* quant, void* stream) {
+    return guarded([&]() -> mpc_status {
+    if (!c || !d_counts || !d_choices || slot < 0 || slot >= mpc_context::kSeqSlots) return fail(MPC_ERR_ARGUMENT, "bad argument");
+    if (c->device < 0) return fail(MPC_ERR_NO_DEVICE, "context was created without a device");
+    if (width < 1 || height < 1) return fail(MPC_ERR_ARGUMENT, "bad geometry");
+    const size_t tiles = static_cast<size_t>((width + 7) / 8) * ((height + 7) / 8), n_tc = tiles * 3;
+    const int K = c->K;
+    std::lock_guard<std::recursive_mutex> one_host_call(c->host_calls);
+    HIP_TRY(hipSetDevice(c->device));
+    ContainerJob* j = job_of(c, slot);
+    if (j->stage != 0) return fail(MPC_ERR_ARGUMENT, "container job slot %d is busy", slot);
+    auto up = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
+    const size_t off_bytes = up(sizeof(unsigned long long) * (6 * static_cast<size_t>(K) + 1));
+    const size_t symbols_bytes = up(sizeof(uint16_t) * 2 * n_tc * K);
+    const size_t live_bytes = up(sizeof(unsigned) * mpc::stream_workspace_words(static_cast<long long>(tiles), K));
+    const size_t sizes_bytes = up(sizeof(unsigned) * 3 * K), dc_bytes = up(sizeof(uint16_t) * n_tc);
+    const size_t dev_need = live_bytes + sizes_bytes + off_bytes + symbols_bytes + dc_bytes;
+    if (dev_need > j->dev_bytes) {
+        HIP_TRY(hipDeviceSynchronize());
+        if (j->dev) (void)hipFree(j->dev);
+        j->dev = nullptr;
+        j->dev_bytes = 0;
+        const hipError_t e = hipMalloc(&j->dev, dev_need);
+        if (e != hipSuccess) return fail(MPC_ERR_ALLOC, "device staging of %zu bytes: %s", dev_need, hipGetErrorString(e));
+        j->dev_bytes = dev_need;
+    }
+    if (!j->phase1) {
+        HIP_TRY(hipEventCreateWithFlags(&j->phase1, hipEventDisableTiming | hipEventBlockingSync));
+        HIP_TRY(hipEventCreateWithFlags(&j->done, hipEventDisableTiming | hipEventBlockingSync));
+    }
+    char* dbase = static_cast<char*>(j->dev);
+    mpc::StreamArgs& sa = j->sa;
+    sa = mpc::StreamArgs{};
     sa.counts = d_counts;
     sa.choices = reinterpret_cast<const uint32_t*>(d_choices);
     sa.tiles = static_cast<long long>(tiles);
@@ -1623,40 +1710,87 @@ mpc_status mpc_records_to_container_device(mpc_context* c, const uint16_t* d_cou
     sa.stream_off = reinterpret_cast<unsigned long long*>(dbase + live_bytes + sizes_bytes);
     sa.symbols = reinterpret_cast<uint16_t*>(dbase + live_bytes + sizes_bytes + off_bytes);
     sa.dc_tmp = reinterpret_cast<uint16_t*>(dbase + live_bytes + sizes_bytes + off_bytes + symbols_bytes);
-    uint16_t* counts = reinterpret_cast<uint16_t*>(hbase);
-    unsigned long long* off = reinterpret_cast<unsigned long long*>(hbase + counts_bytes);
-    uint16_t* symbols = reinterpret_cast<uint16_t*>(hbase + counts_bytes + off_bytes);
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const int err = mpc::launch_stream_assembly(sa, s);
-    if (err != 0) return fail(MPC_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(err)));
-    if (!host_entropy_forced()) {
-        EntropyBuffers eb;
-        const mpc_status es = entropy_buffers(c, 0, tiles, K, &eb);
+    j->width = width;
+    j->height = height;
+    j->d_counts = d_counts;
+    j->stream = static_cast<hipStream_t>(stream);
+    const double* q = quant ? quant : c->quant.data();
+    j->quant.assign(q, q + 3 * static_cast<size_t>(K));
+    j->device_entropy = !host_entropy_forced();
+    if (j->device_entropy) {
+        const mpc_status es = entropy_buffers(c, slot, tiles, K, &j->eb);
         if (es != MPC_OK) return es;
-        eb.args.counts = d_counts;
-        eb.args.symbols = sa.symbols;
-        eb.args.stream_off = sa.stream_off;
-        const int e1 = mpc::launch_entropy_phase1(eb.args, eb.capacity_symbols, s);
-        if (e1 != 0) return fail(MPC_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(e1)));
-        HIP_TRY(hipStreamSynchronize(s));
-        hipEvent_t done = nullptr;
-        HIP_TRY(hipEventCreateWithFlags(&done, hipEventDisableTiming));
-        const EntropyResult r = finish_entropy_on_device(eb, c->block_size, width, height, K, quant ? quant : c->quant.data(), s, done, nullptr, bytes, nbytes);
-        (void)hipEventDestroy(done);
-        if (r == EntropyResult::kDone) return MPC_OK;
-        if (r == EntropyResult::kFailed) return fail(MPC_ERR_HIP, "device entropy stage failed: %s", hipGetErrorString(hipGetLastError()));
     }
-    const size_t n_off = 6 * static_cast<size_t>(K) + 1;
-    HIP_TRY(hipMemcpyAsync(off, sa.stream_off, sizeof(unsigned long long) * n_off, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(counts, d_counts, sizeof(uint16_t) * n_tc, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    const unsigned long long total = off[n_off - 1];
-    if (total > 2ULL * n_tc * static_cast<unsigned long long>(K)) return fail(MPC_ERR_HIP, "stream assembly returned an impossible size");
-    if (total) HIP_TRY(hipMemcpyAsync(symbols, sa.symbols, sizeof(uint16_t) * total, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    *bytes = mpc::encode_symbol_streams_malloc(width, height, K, c->block_size, quant ? quant : c->quant.data(), counts, symbols, off, nbytes);
-    return *bytes ? MPC_OK : fail(MPC_ERR_ALLOC, "out of memory");
+    const int err = mpc::launch_stream_assembly(sa, j->stream);
+    if (err != 0) return fail(MPC_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(err)));
+    if (j->device_entropy) {
+        j->eb.args.counts = d_counts;
+        j->eb.args.symbols = sa.symbols;
+        j->eb.args.stream_off = sa.stream_off;
+        const int e1 = mpc::launch_entropy_phase1(j->eb.args, j->eb.capacity_symbols, j->stream);
+        if (e1 != 0) return fail(MPC_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(e1)));
+    }
+    HIP_TRY(hipEventRecord(j->phase1, j->stream));
+    j->stage = 1;
+    return MPC_OK;
     });
+}
+
+mpc_status mpc_container_job_tables(mpc_context* c, int slot) {
+    return guarded([&]() -> mpc_status {
+    if (!c || slot < 0 || slot >= mpc_context::kSeqSlots) return fail(MPC_ERR_ARGUMENT, "bad argument");
+    std::lock_guard<std::recursive_mutex> one_host_call(c->host_calls);
+    ContainerJob* j = job_of(c, slot);
+    if (j->stage != 1) return fail(MPC_ERR_ARGUMENT, "container job slot %d has not begun", slot);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventSynchronize(j->phase1));
+    std::free(j->blob);
+    j->blob = nullptr;
+    j->nblob = 0;
+    EntropyResult r = EntropyResult::kNeedsHost;
+    if (j->device_entropy) {
+        r = entropy_tables(j->eb, c->block_size, j->width, j->height, c->K, j->quant.data(), j->stream, j->done, &j->pending);
+        if (r == EntropyResult::kFailed) { j->stage = 0; return fail(MPC_ERR_HIP, "device entropy stage failed: %s", hipGetErrorString(hipGetLastError())); }
+    }
+    if (r == EntropyResult::kNeedsHost) {
+        j->device_entropy = false;
+        const mpc_status st = container_on_host(c, j, &j->blob, &j->nblob);
+        if (st != MPC_OK) { j->stage = 0; return st; }
+    }
+    j->stage = 2;
+    return MPC_OK;
+    });
+}
+
+mpc_status mpc_container_job_collect(mpc_context* c, int slot, uint8_t** bytes, size_t* nbytes) {
+    return guarded([&]() -> mpc_status {
+    if (!c || !bytes || !nbytes || slot < 0 || slot >= mpc_context::kSeqSlots) return fail(MPC_ERR_ARGUMENT, "bad argument");
+    std::lock_guard<std::recursive_mutex> one_host_call(c->host_calls);
+    ContainerJob* j = job_of(c, slot);
+    if (j->stage != 2) return fail(MPC_ERR_ARGUMENT, "container job slot %d has no tables yet", slot);
+    HIP_TRY(hipSetDevice(c->device));
+    j->stage = 0;
+    if (!j->device_entropy) {
+        *bytes = j->blob;
+        *nbytes = j->nblob;
+        j->blob = nullptr;
+        j->nblob = 0;
+        return MPC_OK;
+    }
+    const EntropyResult r = entropy_collect(j->eb, j->pending, j->done, bytes, nbytes);
+    return r == EntropyResult::kDone ? MPC_OK : fail(MPC_ERR_HIP, "device entropy stage failed: %s", hipGetErrorString(hipGetLastError()));
+    });
+}
+
+mpc_status mpc_records_to_container_device(mpc_context* c, const uint16_t* d_counts, const mpc_basis_choice* d_choices, int width,
+                                           int height, const double* quant, void* stream, uint8_t** bytes, size_t* nbytes) {
+    if (!bytes || !nbytes) return fail(MPC_ERR_ARGUMENT, "null argument");
+    if (!c) return fail(MPC_ERR_ARGUMENT, "null context");
+    std::lock_guard<std::recursive_mutex> one_host_call(c->host_calls);
+    mpc_status st = mpc_container_job_begin(c, 0, d_counts, d_choices, width, height, quant, stream);
+    if (st == MPC_OK) st = mpc_container_job_tables(c, 0);
+    if (st == MPC_OK) st = mpc_container_job_collect(c, 0, bytes, nbytes);
+    return st;
 }
 
 // The entropy stage alone, on streams the caller holds in host memory (what mpc_assemble_symbol_streams codes on the host):

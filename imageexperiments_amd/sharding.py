@@ -68,8 +68,9 @@ def exchange_stripes(dist, mine, tiles_x, tiles_y, via_cpu=False):
 
 
 class StripedEncoder:
-    """One step of the N > 1 path on a GPU: stripe encode of every frame (one launch), stripe exchange, interleave, this
-    rank's frame -> container bytes (device stream assembly + host entropy stage)."""
+    """The N > 1 path on a GPU: stripe encode of every frame (one launch), stripe exchange, interleave, this rank's frame ->
+    container bytes (stream assembly and the per-symbol entropy work on the device, code tables on the host).  `step` does one
+    step synchronously; `run` pipelines consecutive steps."""
 
     def __init__(self, ctx, width, height, frames, world, rank, backend):
         import torch
@@ -86,7 +87,9 @@ class StripedEncoder:
         self.choices = torch.zeros((frames, per_frame, 3, K), dtype=torch.int32, device="cuda")
         ctx.reserve(frames * per_frame)
 
-    def step(self, d_rgb, stream):
+    def _records_of_my_frame(self, d_rgb, stream):
+        """stripe encode of every frame (one launch), stripe exchange, interleave: whole-frame records of the frame this rank owns,
+        all enqueued on `stream` (RCCL) or synchronous (gloo rehearsal)"""
         W, H = self.W, self.H
         self.ctx.encode_batch_device(d_rgb.data_ptr(), self.world, W * H * 3, W, H, W * 3, self.begin, self.end,
                                      self.counts.data_ptr(), self.choices.data_ptr(), stream=stream.cuda_stream)
@@ -94,7 +97,35 @@ class StripedEncoder:
         hparts = exchange_stripes(self.dist, list(self.choices), self.tiles_x, self.tiles_y, self.via_cpu)
         counts = interleave_stripes(cparts, self.tiles_x, self.tiles_y, self.world).contiguous()
         choices = interleave_stripes(hparts, self.tiles_x, self.tiles_y, self.world).contiguous()
-        return self.ctx.records_to_container_device(counts.data_ptr(), choices.data_ptr(), W, H, stream=stream.cuda_stream)
+        return counts, choices
+
+    def step(self, d_rgb, stream):
+        counts, choices = self._records_of_my_frame(d_rgb, stream)
+        return self.ctx.records_to_container_device(counts.data_ptr(), choices.data_ptr(), self.W, self.H, stream=stream.cuda_stream)
+
+    def run(self, d_rgb, stream, steps, views=False):
+        """`steps` steps, software-pipelined on ONE stream so that the device always has the next tile encode queued: step i's
+        encode + exchange + stream assembly + entropy phase 1 are enqueued, then step i-1's code tables are built on the host
+        (while the device works on step i) and its phase 2 + container copy enqueued behind, then step i-2's container is
+        collected (long finished).  Same containers as `step`, in order."""
+        slots = 3
+        held = [None] * slots                                   # the records a job reads stay alive until its tables are done
+        out = []
+        for i in range(steps):
+            counts, choices = self._records_of_my_frame(d_rgb, stream)
+            held[i % slots] = (counts, choices)
+            self.ctx.container_job_begin(i % slots, counts.data_ptr(), choices.data_ptr(), self.W, self.H, stream=stream.cuda_stream)
+            if i >= 1:
+                self.ctx.container_job_tables((i - 1) % slots)
+            if i >= 2:
+                out.append(self.ctx.container_job_collect((i - 2) % slots, views))
+        if steps >= 1:
+            self.ctx.container_job_tables((steps - 1) % slots)
+        if steps >= 2:
+            out.append(self.ctx.container_job_collect((steps - 2) % slots, views))
+        if steps >= 1:
+            out.append(self.ctx.container_job_collect((steps - 1) % slots, views))
+        return out
 
 
 def histogram_of_records(counts, choices, K):

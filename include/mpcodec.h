@@ -263,6 +263,17 @@ mpc_status mpc_encode_images_device(mpc_context* ctx, const uint8_t* const* d_rg
  * device (on `stream`), live symbols to the host, entropy stage.  Synchronises `stream`. */
 mpc_status mpc_records_to_container_device(mpc_context* ctx, const uint16_t* d_counts, const mpc_basis_choice* d_choices, int width,
                                            int height, const double* quant, void* stream, uint8_t** bytes, size_t* nbytes);
+/* The same in three steps, for a caller that keeps the device busy meanwhile (the multi-GPU path: the next step's tile encode
+ * runs while this frame's code tables are built).  slot in [0, MPC_JOB_SLOTS): one job per slot at a time; the records must
+ * stay untouched until `collect` has returned (the counts are the `lengths` stream the last kernels read).
+ *   begin    stream assembly and the first phase of the entropy stage enqueued on `stream`; nothing is waited for
+ *   tables   waits for that, builds the code tables on the host, enqueues the second phase and the container's copy on `stream`
+ *   collect  waits for the copy; the container (mpc_free) */
+#define MPC_JOB_SLOTS 4
+mpc_status mpc_container_job_begin(mpc_context* ctx, int slot, const uint16_t* d_counts, const mpc_basis_choice* d_choices, int width,
+                                   int height, const double* quant, void* stream);
+mpc_status mpc_container_job_tables(mpc_context* ctx, int slot);
+mpc_status mpc_container_job_collect(mpc_context* ctx, int slot, uint8_t** bytes, size_t* nbytes);
 
 /* matching::FromCoeffsDynamic (MatchingPursuit.h:25) + img::RGBFromYUV for every tile of a frame on the device:
  * records in the reference's order (tile t = tx*tiles_y + ty, as mpc_encode_tiles returns them for the whole

@@ -87,8 +87,13 @@ def _gpu_worker(rank, world, port, W, H, K, q, out_dir):
     for _ in range(2):                                        # twice: buffers are reused from step to step
         blob = enc.step(d_rgb, torch.cuda.current_stream())
     ref = O.OracleContext(K, 8, q).encode_image(frames[rank])
+    verdict = "ok" if bytes(blob) == bytes(ref) else f"bytes differ: {len(blob)} vs {len(ref)}"
+    for steps in (1, 2, 5):                                   # the software-pipelined form (bench.py --gpus N): same containers
+        blobs = enc.run(d_rgb, torch.cuda.current_stream(), steps)
+        if len(blobs) != steps or any(bytes(b) != bytes(ref) for b in blobs):
+            verdict = f"pipelined run of {steps} steps differs"
     with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
-        f.write("ok" if bytes(blob) == bytes(ref) else f"bytes differ: {len(blob)} vs {len(ref)}")
+        f.write(verdict)
     dist.barrier()
     dist.destroy_process_group()
 
