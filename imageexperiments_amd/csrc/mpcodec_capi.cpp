@@ -1445,7 +1445,11 @@ static mpc_status encode_sequence(mpc_context* c, const uint8_t* const* frames, 
     // frame's worker once it has built the tables -- which happens while pursuit(f + 1) runs; pursuit(f + 2) is enqueued only
     // after that (`phase2_enqueued`), so that it cannot slip in front.  The statistics reach the host through mapped memory
     // written by the kernels themselves, the host waits on events only.
+    // Phase 2(f - 1) and the stream assembly + phase 1 of frame f are both chains of small, latency-bound kernels that fall into the
+    // same gap between two pursuits: phase 2 goes to its slot's own stream so that the two chains overlap, and the next pursuit
+    // waits for both (MPC_PHASE2_BESIDE=0: one stream for everything).
     hipStream_t pursuit_stream = c->seq_compute;
+    static const bool phase2_beside = env_int("MPC_PHASE2_BESIDE", 1) != 0;
     std::future<void> phase2_enqueued[S];
     EntropyBuffers ent[S];
     if (device_entropy)
@@ -1480,7 +1484,12 @@ static mpc_status encode_sequence(mpc_context* c, const uint8_t* const* frames, 
         Pending& slot = pending[sl];
         collect(slot);                    // frame f - slots is done with this slot: its download and its entropy stage have finished
         if (st != MPC_OK) break;
-        if (f >= 2 && phase2_enqueued[(f - 2) % static_cast<int>(slots)].valid()) phase2_enqueued[(f - 2) % static_cast<int>(slots)].get();
+        if (f >= 2 && phase2_enqueued[(f - 2) % static_cast<int>(slots)].valid()) {
+            // frame f - 2's phase 2 is on its slot's stream by now: this frame's pursuit starts behind it (the event is the one its
+            // worker recorded behind the container's copy; on the host route it is an old one and the wait is empty)
+            phase2_enqueued[(f - 2) % static_cast<int>(slots)].get();
+            if (phase2_beside) MPC_SEQ_TRY(hipStreamWaitEvent(pursuit_stream, c->seq_events[(f - 2) % static_cast<int>(slots)][2], 0));
+        }
         char* dbase = static_cast<char*>(c->stage) + static_cast<size_t>(sl) * dev_slot;
         char* hbase = static_cast<char*>(c->host_stage) + static_cast<size_t>(sl) * host_slot;
         const uint8_t* d_rgb = frames[f];
@@ -1567,7 +1576,8 @@ static mpc_status encode_sequence(mpc_context* c, const uint8_t* const* frames, 
             if (device_entropy) {
                 uint8_t* blob = nullptr;
                 size_t n = 0;
-                const EntropyResult r = finish_entropy_on_device(eb, bs, width, height, K, q, pursuit_stream, ev_down, [&] { tell(); }, &blob, &n, tr.e);
+                const EntropyResult r = finish_entropy_on_device(eb, bs, width, height, K, q, phase2_beside ? down : pursuit_stream, ev_down,
+                                                                 [&] { tell(); }, &blob, &n, tr.e);
                 tr.t2 = tr.t3 = now_ms();
                 if (r == EntropyResult::kDone) return {blob, n};
                 if (r == EntropyResult::kFailed) return {nullptr, 0};
