@@ -219,9 +219,11 @@ struct mpc_context {
     size_t host_stage_bytes = 0;
     // mpc_encode_images: upload / compute / download streams and per-slot events (upload done, pursuit done, download done)
     hipStream_t seq_up = nullptr, seq_compute = nullptr;
-    static constexpr int kSeqSlots = 4;              // frames in flight in mpc_encode_images
+    static constexpr int kSeqSlots = 6;              // frames in flight in mpc_encode_images (a frame's container is ready about
+                                                     // three pursuits after its own started)
     int pipes_cap = 0;                               // > 0: at most this many concurrent sub-batches per call
     hipEvent_t seq_events[kSeqSlots][3] = {};
+    hipEvent_t seq_pursuit_done[kSeqSlots] = {};      // behind a slot's pursuit, for the slot's own stream to wait on
     hipStream_t seq_down[kSeqSlots] = {};             // one download stream per slot: its worker thread drives it
     // device-side entropy stage (mp_entropy.hip): per-slot buffers (grow-only) and the histogram tables all slots share
     // (phase 1 of every frame runs on one stream, in order)
@@ -589,6 +591,8 @@ void mpc_context_destroy(mpc_context* c) {
         for (auto& slot : c->seq_events)
             for (hipEvent_t e : slot)
                 if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : c->seq_pursuit_done)
+            if (e) (void)hipEventDestroy(e);
         for (auto& p : c->pipes) {
             if (p.mem) (void)hipFree(p.mem);
             if (p.stream) (void)hipStreamDestroy(p.stream);
@@ -1431,6 +1435,7 @@ static mpc_status encode_sequence(mpc_context* c, const uint8_t* const* frames, 
         HIP_TRY(hipStreamCreateWithFlags(&c->seq_up, hipStreamNonBlocking));
         HIP_TRY(hipStreamCreateWithFlags(&c->seq_compute, hipStreamNonBlocking));
         for (auto& s : c->seq_down) HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        for (hipEvent_t& e : c->seq_pursuit_done) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         // blocking events: a thread waiting for the device sleeps instead of spinning (the entropy stage wants the cores)
         for (auto& slot : c->seq_events)
             for (hipEvent_t& e : slot) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventBlockingSync));
@@ -1450,6 +1455,11 @@ static mpc_status encode_sequence(mpc_context* c, const uint8_t* const* frames, 
     // waits for both (MPC_PHASE2_BESIDE=0: one stream for everything).
     hipStream_t pursuit_stream = c->seq_compute;
     static const bool phase2_beside = env_int("MPC_PHASE2_BESIDE", 1) != 0;
+    // One step further (MPC_ASSEMBLY_BESIDE, needs the above): the stream assembly + phase 1 of frame f go to the slot's stream as
+    // well, and pursuit(f + 1) starts right behind pursuit(f).  A pursuit's last millisecond leaves more and more CUs idle (its
+    // chroma workgroups run out of tile-channels one by one); the small kernels of frames f - 1 (assembly, phase 1) and f - 2
+    // (phase 2, copy) fill that tail.  Pursuit(f) waits for the assembly of f - 2 and the phase 2 of f - 3, so nothing piles up.
+    static const bool assembly_beside = phase2_beside && env_int("MPC_ASSEMBLY_BESIDE", 1) != 0;
     std::future<void> phase2_enqueued[S];
     EntropyBuffers ent[S];
     if (device_entropy)
@@ -1484,12 +1494,14 @@ static mpc_status encode_sequence(mpc_context* c, const uint8_t* const* frames, 
         Pending& slot = pending[sl];
         collect(slot);                    // frame f - slots is done with this slot: its download and its entropy stage have finished
         if (st != MPC_OK) break;
-        if (f >= 2 && phase2_enqueued[(f - 2) % static_cast<int>(slots)].valid()) {
-            // frame f - 2's phase 2 is on its slot's stream by now: this frame's pursuit starts behind it (the event is the one its
-            // worker recorded behind the container's copy; on the host route it is an old one and the wait is empty)
-            phase2_enqueued[(f - 2) % static_cast<int>(slots)].get();
-            if (phase2_beside) MPC_SEQ_TRY(hipStreamWaitEvent(pursuit_stream, c->seq_events[(f - 2) % static_cast<int>(slots)][2], 0));
+        const int back = assembly_beside ? 3 : 2;
+        if (f >= back && phase2_enqueued[(f - back) % static_cast<int>(slots)].valid()) {
+            // frame f - back's phase 2 is on its slot's stream by now: this frame's pursuit starts behind it (the event is the one
+            // its worker recorded behind the container's copy; on the host route it is an old one and the wait is empty)
+            phase2_enqueued[(f - back) % static_cast<int>(slots)].get();
+            if (phase2_beside) MPC_SEQ_TRY(hipStreamWaitEvent(pursuit_stream, c->seq_events[(f - back) % static_cast<int>(slots)][2], 0));
         }
+        if (assembly_beside && f >= 2) MPC_SEQ_TRY(hipStreamWaitEvent(pursuit_stream, c->seq_events[(f - 2) % static_cast<int>(slots)][1], 0));
         char* dbase = static_cast<char*>(c->stage) + static_cast<size_t>(sl) * dev_slot;
         char* hbase = static_cast<char*>(c->host_stage) + static_cast<size_t>(sl) * host_slot;
         const uint8_t* d_rgb = frames[f];
@@ -1534,17 +1546,22 @@ static mpc_status encode_sequence(mpc_context* c, const uint8_t* const* frames, 
         st = mpc_encode_tiles_device(c, d_rgb, width, height, static_cast<size_t>(3) * width, 0, tiles_y, quant, d_counts, d_choices,
                                      nullptr, nullptr, 0, pursuit_stream);
         if (st != MPC_OK) break;
-        hipStream_t down = c->seq_down[sl];       // the host route's copies
-        MPC_SEQ_TRY(static_cast<hipError_t>(mpc::launch_stream_assembly(sa, pursuit_stream)));
+        hipStream_t down = c->seq_down[sl];       // phase 2, the host route's copies; with assembly_beside everything behind the pursuit
+        hipStream_t behind = assembly_beside ? down : pursuit_stream;
+        if (assembly_beside) {
+            MPC_SEQ_TRY(hipEventRecord(c->seq_pursuit_done[sl], pursuit_stream));
+            MPC_SEQ_TRY(hipStreamWaitEvent(down, c->seq_pursuit_done[sl], 0));
+        }
+        MPC_SEQ_TRY(static_cast<hipError_t>(mpc::launch_stream_assembly(sa, behind)));
         EntropyBuffers eb = ent[sl];
         if (device_entropy) {
             eb.args.counts = d_counts;
             eb.args.symbols = sa.symbols;
             eb.args.stream_off = sa.stream_off;
-            MPC_SEQ_TRY(static_cast<hipError_t>(mpc::launch_entropy_phase1(eb.args, eb.capacity_symbols, pursuit_stream)));
+            MPC_SEQ_TRY(static_cast<hipError_t>(mpc::launch_entropy_phase1(eb.args, eb.capacity_symbols, behind)));
         }
         hipEvent_t ev_comp = c->seq_events[sl][1];
-        MPC_SEQ_TRY(hipEventRecord(ev_comp, pursuit_stream));
+        MPC_SEQ_TRY(hipEventRecord(ev_comp, behind));
         auto told = std::make_shared<std::promise<void>>();
         phase2_enqueued[sl] = told->get_future();
         const int bs = c->block_size, device = c->device;

@@ -269,7 +269,7 @@ mpc_status mpc_records_to_container_device(mpc_context* ctx, const uint16_t* d_c
  *   begin    stream assembly and the first phase of the entropy stage enqueued on `stream`; nothing is waited for
  *   tables   waits for that, builds the code tables on the host, enqueues the second phase and the container's copy on `stream`
  *   collect  waits for the copy; the container (mpc_free) */
-#define MPC_JOB_SLOTS 4
+#define MPC_JOB_SLOTS 6
 mpc_status mpc_container_job_begin(mpc_context* ctx, int slot, const uint16_t* d_counts, const mpc_basis_choice* d_choices, int width,
                                    int height, const double* quant, void* stream);
 mpc_status mpc_container_job_tables(mpc_context* ctx, int slot);

@@ -11,8 +11,9 @@ pipe = [i for k, i in enumerate(idx[:-1]) if any("mp_stream_count" in rows[j]["K
 a, b = pipe[-5], pipe[-3]
 t0 = int(rows[a]["Start_Timestamp"])
 out = ["# bench.py: two consecutive frames of the timed call in steady state, every kernel the device ran (rocprofv3 --kernel-trace)\n"
-       "# start_ms end_ms duration_ms kernel   -- one ordered queue: pursuit(f) | stream assembly + entropy phase 1 (f) | "
-       "phase 2 + container copy (f-1) | pursuit(f+1) ...\n"]
+       "# start_ms end_ms duration_ms kernel   -- pursuits back to back on one stream; behind each, on its slot's stream: stream "
+       "assembly + entropy phase 1 (f), later phase 2 + container copy (f); they run in the next pursuits' tails (a kernel's "
+       "start is its dispatch: a long 'duration' of a small kernel is time spent waiting for a free CU)\n"]
 for r in rows[a:b + 1]:
     s, e = (int(r["Start_Timestamp"]) - t0) / 1e6, (int(r["End_Timestamp"]) - t0) / 1e6
     name = r["Kernel_Name"].split("(")[0].replace("mpc::", "").replace("void ", "")
