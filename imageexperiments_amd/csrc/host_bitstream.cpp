@@ -613,10 +613,32 @@ bool huffman_decode(BitReader& in, std::vector<uint16_t>& out) {
                 if (lut[lo + fill] == 0) lut[lo + fill] = ((first_index[l] + k) << 5) | static_cast<uint32_t>(l);
         }
     }
+    // two symbols per look-up where two whole codes (neither the pseudo-EOF) fit the window: same symbols in the same order
+    std::vector<uint32_t> pair_symbols(lut.size(), 0);
+    std::vector<uint8_t> pair_bits(lut.size(), 0);
+    const uint32_t eof_entry = static_cast<uint32_t>(total) - 1u;
+    for (uint32_t w = 0; w < lut.size(); ++w) {
+        const uint32_t h1 = lut[w];
+        if (h1 == 0 || (h1 >> 5) == eof_entry) continue;
+        const uint32_t l1 = h1 & 31u;
+        if (l1 >= static_cast<uint32_t>(kLutBits)) continue;
+        const uint32_t h2 = lut[(w << l1) & (static_cast<uint32_t>(lut.size()) - 1u)];
+        if (h2 == 0 || (h2 >> 5) == eof_entry || l1 + (h2 & 31u) > static_cast<uint32_t>(kLutBits)) continue;
+        pair_symbols[w] = static_cast<uint32_t>(table[h1 >> 5]) | (static_cast<uint32_t>(table[h2 >> 5]) << 16);
+        pair_bits[w] = static_cast<uint8_t>(l1 + (h2 & 31u));
+    }
     for (;;) {
         const size_t left = in.remaining();
         if (left == 0) return false;
         const uint32_t window = in.peek32();
+        const uint32_t both = pair_bits[window >> (32 - kLutBits)];
+        if (both != 0 && both <= left) {
+            const uint32_t syms = pair_symbols[window >> (32 - kLutBits)];
+            out.push_back(static_cast<uint16_t>(syms & 0xFFFFu));
+            out.push_back(static_cast<uint16_t>(syms >> 16));
+            in.skip(both);
+            continue;
+        }
         uint32_t entry = 0;
         int used = 0;
         const uint32_t hit = lut[window >> (32 - kLutBits)];
