@@ -508,9 +508,9 @@ class CompressionContext:
         _check(self.L.mpc_encode_image(self.h, rgb.ctypes.data_as(_u8p), W, H, qp, C.byref(out), C.byref(n)))
         return _take_bytes(self.L, out, n)
 
-    def encode_images(self, frames, quant=None):
-        """encodeImage for a sequence of equally sized frames, host entropy stage of frame n overlapped with the device
-        encode of frame n+1 (mpc_encode_images).  Returns a list of bytes objects."""
+    def encode_images(self, frames, quant=None, views=False):
+        """encodeImage for a sequence of equally sized frames in host memory, pipelined (mpc_encode_images).  Returns a list of
+        bytes objects; views=True: read-only uint8 arrays on the library's buffers (no Python-side copy)."""
         frames = [np.ascontiguousarray(f, np.uint8) for f in frames]
         H, W = frames[0].shape[:2]
         if any(f.shape[:2] != (H, W) for f in frames):
@@ -524,7 +524,8 @@ class CompressionContext:
         outs = (_u8p * n)()
         sizes = (C.c_size_t * n)()
         _check(self.L.mpc_encode_images(self.h, ptrs, n, W, H, qp, outs, sizes))
-        return [_take_bytes(self.L, outs[i], C.c_size_t(sizes[i])) for i in range(n)]
+        take = _take_view if views else _take_bytes
+        return [take(self.L, outs[i], C.c_size_t(sizes[i])) for i in range(n)]
 
     def encode_images_device(self, d_frames, width, height, quant=None, views=False):
         """mpc_encode_images_device: frames already in device memory (ints from tensor.data_ptr(), tightly packed RGB).

@@ -1489,6 +1489,37 @@ static mpc_status encode_sequence(mpc_context* c, const uint8_t* const* frames, 
         const hipError_t e_ = (call);                                                             \
         if (e_ != hipSuccess) { st = fail(MPC_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); break; } \
     }
+    // Host frames: frame g is copied into its slot's pinned image by a few threads (the caller's memory is pageable: the runtime
+    // would stage it through one thread at a few GB/s) and sent to the device while frame g - 1 is still being enqueued and
+    // encoded; its pursuit waits for the event behind the copy.
+    std::future<hipError_t> uploads[S];
+    auto start_upload = [&](int g) {
+        const int usl = g % static_cast<int>(slots);
+        collect(pending[usl]);            // the slot's previous frame is through
+        uint8_t* d_img = reinterpret_cast<uint8_t*>(static_cast<char*>(c->stage) + static_cast<size_t>(usl) * dev_slot);
+        uint8_t* pinned_rgb = reinterpret_cast<uint8_t*>(static_cast<char*>(c->host_stage) + static_cast<size_t>(usl) * host_slot);
+        const uint8_t* src = frames[g];
+        hipEvent_t ev_up = c->seq_events[usl][0];
+        hipStream_t up_stream = c->seq_up;
+        const int device = c->device;
+        uploads[usl] = std::async(std::launch::async, [=]() -> hipError_t {
+            constexpr int kCopiers = 8;
+            const size_t piece = ((img_bytes + kCopiers - 1) / kCopiers + 4095) & ~static_cast<size_t>(4095);
+            std::future<void> parts[kCopiers];
+            for (int k = 1; k < kCopiers; ++k) {
+                const size_t lo = std::min(img_bytes, piece * k), hi = std::min(img_bytes, piece * (k + 1));
+                if (hi > lo) parts[k] = std::async(std::launch::async, [=] { std::memcpy(pinned_rgb + lo, src + lo, hi - lo); });
+            }
+            std::memcpy(pinned_rgb, src, std::min(img_bytes, piece));
+            for (int k = 1; k < kCopiers; ++k)
+                if (parts[k].valid()) parts[k].get();
+            hipError_t e = hipSetDevice(device);
+            if (e == hipSuccess) e = hipMemcpyAsync(d_img, pinned_rgb, img_bytes, hipMemcpyHostToDevice, up_stream);
+            if (e == hipSuccess) e = hipEventRecord(ev_up, up_stream);
+            return e;
+        });
+    };
+    if (!on_device) start_upload(0);
     for (int f = 0; f < n_frames && st == MPC_OK; ++f) {
         const int sl = f % static_cast<int>(slots);
         Pending& slot = pending[sl];
@@ -1507,25 +1538,12 @@ static mpc_status encode_sequence(mpc_context* c, const uint8_t* const* frames, 
         const uint8_t* d_rgb = frames[f];
         if (!on_device) {
             uint8_t* d_img = reinterpret_cast<uint8_t*>(dbase);
-            uint8_t* pinned_rgb = reinterpret_cast<uint8_t*>(hbase);
             dbase += up(img_bytes);
             hbase += up(img_bytes);
-            // the caller's frame is pageable: the runtime would stage it through one thread at a few GB/s while this thread
-            // waits; a few threads copy it into the slot's pinned image instead and the DMA runs asynchronously
-            constexpr int kCopiers = 4;
-            const size_t piece = ((img_bytes + kCopiers - 1) / kCopiers + 4095) & ~static_cast<size_t>(4095);
-            std::future<void> parts[kCopiers];
-            const uint8_t* src = frames[f];
-            for (int k = 1; k < kCopiers; ++k) {
-                const size_t lo = std::min(img_bytes, piece * k), hi = std::min(img_bytes, piece * (k + 1));
-                if (hi > lo) parts[k] = std::async(std::launch::async, [=] { std::memcpy(pinned_rgb + lo, src + lo, hi - lo); });
-            }
-            std::memcpy(pinned_rgb, src, std::min(img_bytes, piece));
-            for (int k = 1; k < kCopiers; ++k)
-                if (parts[k].valid()) parts[k].get();
-            MPC_SEQ_TRY(hipMemcpyAsync(d_img, pinned_rgb, img_bytes, hipMemcpyHostToDevice, c->seq_up));
-            MPC_SEQ_TRY(hipEventRecord(c->seq_events[sl][0], c->seq_up));
+            MPC_SEQ_TRY(uploads[sl].get());
             MPC_SEQ_TRY(hipStreamWaitEvent(pursuit_stream, c->seq_events[sl][0], 0));
+            if (f + 1 < n_frames) start_upload(f + 1);
+            if (st != MPC_OK) break;
             d_rgb = d_img;
         }
         uint16_t* d_counts = reinterpret_cast<uint16_t*>(dbase);
@@ -1615,6 +1633,8 @@ static mpc_status encode_sequence(mpc_context* c, const uint8_t* const* frames, 
         });
     }
 #undef MPC_SEQ_TRY
+    for (auto& u : uploads)
+        if (u.valid()) (void)u.get();
     for (int f = n_frames; f < n_frames + static_cast<int>(slots); ++f) collect(pending[f % static_cast<int>(slots)]);   // oldest first
     (void)hipStreamSynchronize(c->seq_up);
     (void)hipStreamSynchronize(pursuit_stream);
