@@ -39,10 +39,16 @@ FRAMES = [
     ("natural_jpg_k32_q3.5", "jpg", 4928, 3264, 32, 3.5, 0),
     ("odd_1003x517_k32_q3.5", "synthetic", 1003, 517, 32, 3.5, 777),      # ragged edges in both directions
     ("batch_frame1_k32_q3.5", "synthetic", 4928, 3264, 32, 3.5, 12346),   # configs[3]: frame f uses seed 12345 + f
-] + [(f"raise_k32_q{q:.1f}", "synthetic", 4928, 3264, 32, q, 12345) for q in (2.0, 2.5, 3.0, 3.5, 4.0, 4.5, 5.0, 5.5, 6.0)]
+] + [(f"raise_k32_q{q:.1f}", "synthetic", 4928, 3264, 32, q, 12345) for q in (2.0, 2.5, 3.0, 3.5, 4.0, 4.5, 5.0, 5.5, 6.0)] + [
+    # the `...Fast` (float) flavour, by oracle/mpo_fast.c: a DEFINITION of the float mode, parity unpinned against the reference
+    ("fast_1080p_k8_q3.5", "synthetic", 1920, 1080, 8, 3.5, 12345),
+    ("fast_raise_k32_q3.5", "synthetic", 4928, 3264, 32, 3.5, 12345),
+    ("fast_natural_mn_k32_q3.5", "mn", 4928, 3264, 32, 3.5, 0),
+]
 
 _ctx = None
 _rgb = None
+_keep = None
 
 
 def load_frame(kind, W, H, seed):
@@ -58,11 +64,14 @@ def load_frame(kind, W, H, seed):
     raise ValueError(kind)
 
 
-def _init(K, q, shm_name, shape):
-    global _ctx, _rgb
+def _init(K, q, shm_name, shape, fast=False):
+    global _ctx, _rgb, _keep
     from multiprocessing import shared_memory
     from oracle import oracle_py as O
     _ctx = O.OracleContext(K, 8, q)
+    if fast:
+        _keep = _ctx                                     # the float copies refer to the double context's tables
+        _ctx = O.OracleFastContext(_ctx)
     shm = shared_memory.SharedMemory(name=shm_name)
     _rgb = (shm, np.ndarray(shape, np.uint8, buffer=shm.buf))
 
@@ -76,7 +85,7 @@ def _work(rng):
     return a, counts[sl].copy(), delta[sl].copy(), coef[sl].copy(), swept[sl].copy()
 
 
-def encode_frame(rgb, K, q, workers):
+def encode_frame(rgb, K, q, workers, fast=False):
     """-> (container bytes, counts[T][3], delta[T][3][K], coef[T][3][K], swept[T][3]) by the oracle, column-parallel."""
     from multiprocessing import shared_memory
     from oracle import oracle_py as O
@@ -87,7 +96,7 @@ def encode_frame(rgb, K, q, workers):
         np.ndarray(rgb.shape, np.uint8, buffer=shm.buf)[:] = rgb
         step = max(1, tx // (workers * 6))
         ranges = [(a, min(a + step, tx)) for a in range(0, tx, step)]
-        with mp.get_context("fork").Pool(workers, initializer=_init, initargs=(K, q, shm.name, rgb.shape)) as pool:
+        with mp.get_context("fork").Pool(workers, initializer=_init, initargs=(K, q, shm.name, rgb.shape, fast)) as pool:
             parts = pool.map(_work, ranges, chunksize=1)
     finally:
         shm.close()
@@ -139,9 +148,10 @@ def main():
         t0 = time.time()
         rgb = load_frame(kind, W, H, seed)
         assert rgb.shape == (H, W, 3), rgb.shape
-        blob, counts, delta, coef, swept, lens = encode_frame(rgb, K, q, args.workers)
+        fast = name.startswith("fast_")
+        blob, counts, delta, coef, swept, lens = encode_frame(rgb, K, q, args.workers, fast)
         out[name] = {
-            "kind": kind, "width": W, "height": H, "K": K, "quality": q, "seed": seed,
+            "kind": kind, "width": W, "height": H, "K": K, "quality": q, "seed": seed, "flavour": "fast" if fast else "double",
             "rgb_sha256": hashlib.sha256(rgb.tobytes()).hexdigest(),
             "container_sha256": hashlib.sha256(blob).hexdigest(),
             "container_bytes": len(blob),
