@@ -55,7 +55,7 @@ sys.path.insert(0, {root!r})
 import imageexperiments_amd as ia
 from bench import synth_frame
 ctx = ia.create_compression_context(8, 8, 3.5, device=0)
-frames = [synth_frame(328, 200, 12345 + f) for f in range(5)]
+frames = [synth_frame(328, 200, 12345 + f) for f in range(9)]
 blobs = ctx.encode_images(frames)
 print(" ".join(hashlib.sha256(b).hexdigest() for b in blobs))
 """
@@ -63,13 +63,15 @@ print(" ".join(hashlib.sha256(b).hexdigest() for b in blobs))
 
 def test_host_route_gives_the_same_bytes(ia, oracle):
     """MPC_HOST_ENTROPY=1 (the route taken when a stream is outside what the device tables hold) against the device route and
-    the oracle, five pipelined frames."""
+    the oracle, nine pipelined frames (more than the pipeline has slots)."""
     import hashlib
     from bench import synth_frame
     octx = oracle.OracleContext(8, 8, 3.5)
-    want = [hashlib.sha256(octx.encode_image(synth_frame(328, 200, 12345 + f))).hexdigest() for f in range(5)]
+    want = [hashlib.sha256(octx.encode_image(synth_frame(328, 200, 12345 + f))).hexdigest() for f in range(9)]
     # forced from the start; taken behind a completed phase 1 (more distinct symbols than the triple list may hold); device
-    for env in ({"MPC_HOST_ENTROPY": "1"}, {"MPC_ENTROPY_TRIPLES": "50"}, {"MPC_HOST_ENTROPY": "0"}):
+    # ... and the frame pipeline's other schedules (everything on one stream; only phase 2 beside it)
+    for env in ({"MPC_HOST_ENTROPY": "1"}, {"MPC_ENTROPY_TRIPLES": "50"}, {"MPC_HOST_ENTROPY": "0"}, {"MPC_PHASE2_BESIDE": "0"},
+                {"MPC_ASSEMBLY_BESIDE": "0"}):
         r = subprocess.run([sys.executable, "-c", _CHILD.format(root=ROOT)], capture_output=True, text=True, timeout=600,
                            env={**os.environ, **env})
         assert r.returncode == 0, r.stderr
