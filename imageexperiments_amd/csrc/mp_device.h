@@ -1,25 +1,15 @@
-// mp_device.h -- product: device-side data layout and launchers of the MI355X (gfx950)
-// quantized matching-pursuit tile encoder.
+// mp_device.h -- product: device-side data layout and launchers of the MI355X (gfx950) quantized matching-pursuit tile
+// encoder and of the stages behind it.
 //
-// The pursuit is run STEP-SYNCHRONOUSLY over a batch of tile-channels (one 8x8 tile of one of Y/U/V):
-// every MP step is a short sequence of kernels over the tile-channels that are still active.
-//
-//   init      gather tile + YUVFromRGB -> residual r[tc][64], reset state        (CompressedImage.cpp:538-554)
-//   per step s = 0..K-1:
-//     fill     (s>0) prefix-sum the per-block item counts (every workgroup for itself; workgroup 0 emits the chunk
-//              descriptors), scatter (tile-channel, block) items into their block's bucket
-//     filter   the 510 shared base atoms and (s>0) DetailBasis[0], the block the DC atom unlocks for nearly every
-//              tile (no bucketing): best exact projection of each                  (Select, MatchingPursuit.cpp:7-25)
-//     detail   (s>0) every other unlocked detail block, bucketed by (channel, block)
-//     finish   argmax in dictionary order, quantise, record, unlock block, compact  (MatchingPursuit.cpp:55-71)
-//     update   residual update                                                      (mathvector.cpp:116-148)
-//   after the last step, if asked for: energy  sum of squares of every final residual (diagnostic)
-// filter/detail find the maximum without correlating every row in double: bf16 matrix-core approximations with a
-// proven error bound select the one or two rows per tile-channel that can win, and only those are evaluated in the
-// reference's sequential double arithmetic (mp_kernels.hip).  The exhaustive double sweeps remain as a cross-check.
-// The base rows are common to all tile-channels; detail blocks differ per tile-channel, so the (tile-channel,
-// block) pairs of a step are bucketed by block and one MFMA operand tile serves 16 tile-channels of ONE bucket.
-// Active tile-channels are kept in per-channel lists (the detail rows are per channel).
+//   mp_pursuit.hip   the PERSISTENT pursuit kernel (the product's path): one launch runs all K steps of every tile-channel of a
+//                    batch on chip -- LDS-resident dictionary, split-bf16 MFMA screen with a proven bound, Gram-updated detail
+//                    blocks, exact evaluation of the survivors in the reference's arithmetic (PursuitArgs, launch_pursuit)
+//   mp_streams.hip   stream assembly: the records -> the container's 6K symbol streams, live symbols only (StreamArgs)
+//   mp_entropy.hip   the per-symbol work of the entropy stage: run lengths, histograms, first appearances, code writing (EntropyArgs)
+//   mp_kernels.hip   the decoder, the symbol histogram, and the STEP-SYNCHRONOUS pursuit of round 1 (a short sequence of kernels
+//                    per MP step over the active tile-channels: init, fill, filter, detail, finish, update), kept behind
+//                    MPC_PATH=steps / MPC_FILTER=0 as the product's own cross-check (its exhaustive double sweeps need no screen)
+// The step-synchronous kernels' layout follows (Workspace, enqueue_pursuit); the persistent kernel's is further down.
 #pragma once
 #include <cstddef>
 #include <cstdint>

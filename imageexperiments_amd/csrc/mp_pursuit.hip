@@ -1,10 +1,10 @@
 // mp_pursuit.hip -- product: the PERSISTENT matching-pursuit kernel of the MI355X (gfx950, wave64) tile encoder.
 //
-// One launch per channel runs the whole K-step pursuit (CalcMPDynamic, MatchingPursuit.cpp:39-74) of every tile-channel of
-// that channel; nothing of a tile-channel's state leaves the chip between steps:
-//   * a workgroup (8 waves, one per CU) keeps the filter copy of the 510 base rows and of DetailBasis[0] of its channel in
+// One launch runs the whole K-step pursuit (CalcMPDynamic, MatchingPursuit.cpp:39-74) of every tile-channel of a batch (its
+// workgroups are split over the three channels); nothing of a tile-channel's state leaves the chip between steps:
+//   * a workgroup (12 waves, one per CU) keeps the filter copy of the 510 base rows and of DetailBasis[0] of its channel in
 //     LDS (36 tiles of 16 rows x 64 pixels, split-bfloat16 in MFMA operand order, 144 KiB) for its whole life;
-//   * a wave owns kGroups column groups of 16 tile-channels; lane (slot = l & 15, h = l >> 4) holds pixels 16h .. 16h+15 of the
+//   * a wave owns kGroups (= 1) column groups of 16 tile-channels; lane (slot = l & 15, h = l >> 4) holds pixels 16h .. 16h+15 of the
 //     residual of tile-channel `slot` in double (32 VGPRs per group) -- which is at once the B operand slice of
 //     v_mfma_f32_16x16x32_bf16 (k order 16h + 8kk + j, host_dictionary.h: filter_tiles k_order 1) and a quarter of the
 //     reference's sequential dot product;
