@@ -781,7 +781,10 @@ void plan_stream(bool rle_flag, bool shorter, uint32_t rle_size, size_t n, uint3
     int best_m = -1;
     for (int m = 1; m < 2048; m = (m & 1) ? m + 1 : (m << 1) - 1) {
         size_t estimate = 16;
-        for (uint16_t s : st.distinct) estimate += static_cast<size_t>(st.hist[s]) * golomb_length(s, static_cast<uint32_t>(m));
+        for (uint16_t s : st.distinct) {                        // a candidate is out as soon as its partial sum reaches the best so far
+            estimate += static_cast<size_t>(st.hist[s]) * golomb_length(s, static_cast<uint32_t>(m));
+            if (estimate >= best) break;
+        }
         if (estimate < best) { best = estimate; best_m = m; }
     }
     if (best_m < 0) {
@@ -806,20 +809,29 @@ void plan_stream(bool rle_flag, bool shorter, uint32_t rle_size, size_t n, uint3
     }
 }
 
-void or_bits(uint8_t* dst, size_t bit_offset, const BitWriter& piece) {
+void or_bits(uint8_t* dst, size_t dst_bytes, size_t bit_offset, const BitWriter& piece) {
     const size_t nbits = piece.bit_size();
-    const uint64_t* src = piece.words();
-    for (size_t done = 0; done < nbits; done += 64) {           // 64 source bits at a time, byte by byte into place
+    const uint64_t* src = piece.words();                        // MSB first, zero beyond nbits
+    for (size_t done = 0; done < nbits; done += 64) {
         const uint64_t word = src[done >> 6];
-        const size_t take = std::min<size_t>(64, nbits - done);
-        size_t at = bit_offset + done;
+        const size_t at = bit_offset + done, byte = at >> 3;
+        const int sh = static_cast<int>(at & 7);
+        if (byte + 9 <= dst_bytes) {                            // 64 bits at once: eight bytes and the spill into a ninth
+            uint64_t have;
+            std::memcpy(&have, dst + byte, 8);
+            have |= __builtin_bswap64(word >> sh);
+            std::memcpy(dst + byte, &have, 8);
+            if (sh) dst[byte + 8] |= static_cast<uint8_t>((word << (64 - sh)) >> 56);
+            continue;
+        }
+        const size_t take = std::min<size_t>(64, nbits - done);   // near the end of the buffer: bit ranges, byte by byte
+        size_t pos = at;
         for (size_t k = 0; k < take;) {
-            const size_t byte = at >> 3;
-            const int off = static_cast<int>(at & 7);
+            const int off = static_cast<int>(pos & 7);
             const int width = static_cast<int>(std::min<size_t>(8 - off, take - k));
             const uint8_t bits = static_cast<uint8_t>((word >> (64 - k - width)) & ((1u << width) - 1u));
-            dst[byte] |= static_cast<uint8_t>(bits << (8 - off - width));
-            at += static_cast<size_t>(width);
+            dst[pos >> 3] |= static_cast<uint8_t>(bits << (8 - off - width));
+            pos += static_cast<size_t>(width);
             k += static_cast<size_t>(width);
         }
     }
@@ -1222,15 +1234,15 @@ uint8_t* encode_symbol_streams_by_plan_malloc(int width, int height, int K, int 
     *nbytes = (total + 7) / 8;
     uint8_t* dst = static_cast<uint8_t*>(std::calloc(*nbytes ? *nbytes : 1, 1));
     if (!dst) return nullptr;
-    or_bits(dst, 0, head);
+    or_bits(dst, *nbytes, 0, head);
     size_t at = head.bit_size();
     for (int j = 0; j < S; ++j) {
         const StreamPlan& p = plans[static_cast<size_t>(j)];
-        or_bits(dst, at, p.pre);
+        or_bits(dst, *nbytes, at, p.pre);
         at += p.pre.bit_size();
-        or_bits(dst, at, payload[static_cast<size_t>(j)]);
+        or_bits(dst, *nbytes, at, payload[static_cast<size_t>(j)]);
         at += p.payload_bits;
-        or_bits(dst, at, p.post);
+        or_bits(dst, *nbytes, at, p.post);
         at += p.post.bit_size();
     }
     return dst;

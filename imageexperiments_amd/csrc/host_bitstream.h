@@ -112,8 +112,8 @@ struct StreamPlan {
 void plan_stream(bool rle_flag, bool shorter, uint32_t rle_size, size_t n, uint32_t largest, const uint32_t* triples, size_t distinct,
                  StreamPlan& plan);
 BitWriter container_head(int width, int height, int K, int block_size, const double* quant /*[3*K]*/);
-// dst |= piece, MSB first, at bit_offset (dst: the container's bytes)
-void or_bits(uint8_t* dst, size_t bit_offset, const BitWriter& piece);
+// dst |= piece, MSB first, at bit_offset (dst: the container's bytes, dst_bytes of them writable)
+void or_bits(uint8_t* dst, size_t dst_bytes, size_t bit_offset, const BitWriter& piece);
 // body(0..n-1) on the entropy stage's worker pool
 void parallel_jobs(int n, const std::function<void(int)>& body);
 

@@ -1305,7 +1305,11 @@ EntropyResult entropy_tables(const EntropyBuffers& b, int device_block_size, int
     stamp(0);
     std::vector<mpc::StreamPlan>& plans = pending->plans;
     plans.assign(static_cast<size_t>(S), mpc::StreamPlan());
-    mpc::parallel_jobs(S, [&](int j) {
+    std::vector<int> order(static_cast<size_t>(S));             // the streams with the most symbols to build a tree from first
+    for (int j = 0; j < S; ++j) order[static_cast<size_t>(j)] = j;
+    std::sort(order.begin(), order.end(), [&](int x, int y) { return b.h_streams[x].distinct > b.h_streams[y].distinct; });
+    mpc::parallel_jobs(S, [&](int job) {
+        const int j = order[static_cast<size_t>(job)];
         const mpc::EntStream& st = b.h_streams[j];
         mpc::plan_stream(j != 0, st.shorter != 0, st.rle_size, st.eff_n, st.largest, b.h_triples + 3 * static_cast<size_t>(st.triple_off),
                          st.distinct, plans[static_cast<size_t>(j)]);
@@ -1354,16 +1358,24 @@ EntropyResult entropy_collect(const EntropyBuffers& b, const EntropyPending& pen
     const int S = b.args.n_streams;
     for (int j = 0; j < S; ++j)                                 // the device wrote exactly the bits the tables promise
         if (b.h_streams[j].coded_bits != pending.plans[static_cast<size_t>(j)].payload_bits) return EntropyResult::kFailed;
-    mpc::or_bits(b.h_out, 0, pending.head);
+    mpc::or_bits(b.h_out, b.out_capacity, 0, pending.head);
     for (int j = 0; j < S; ++j) {
         const mpc::StreamPlan& p = pending.plans[static_cast<size_t>(j)];
         const unsigned long long payload = b.h_streams[j].bit_off;
-        mpc::or_bits(b.h_out, static_cast<size_t>(payload - p.pre.bit_size()), p.pre);
-        mpc::or_bits(b.h_out, static_cast<size_t>(payload + p.payload_bits), p.post);
+        mpc::or_bits(b.h_out, b.out_capacity, static_cast<size_t>(payload - p.pre.bit_size()), p.pre);
+        mpc::or_bits(b.h_out, b.out_capacity, static_cast<size_t>(payload + p.payload_bits), p.post);
     }
     uint8_t* out = static_cast<uint8_t*>(std::malloc(pending.total_bytes ? pending.total_bytes : 1));
     if (!out) return EntropyResult::kFailed;
-    std::memcpy(out, b.h_out, pending.total_bytes);
+    {   // fresh pages: a few threads fault them in and copy
+        const size_t total = pending.total_bytes, piece = ((total + 7) / 8 + 4095) & ~static_cast<size_t>(4095);
+        const uint8_t* src = b.h_out;
+        mpc::parallel_jobs(total > (1u << 20) ? 8 : 1, [&](int k) {
+            const size_t lo = std::min(total, piece * static_cast<size_t>(k));
+            const size_t hi = total > (1u << 20) ? std::min(total, lo + piece) : total;
+            if (hi > lo) std::memcpy(out + lo, src + lo, hi - lo);
+        });
+    }
     *blob = out;
     *nbytes = pending.total_bytes;
     return EntropyResult::kDone;
