@@ -479,15 +479,27 @@ void huffman_table(const SymbolStats& st, size_t n, BitWriter& out, HuffmanTable
         std::push_heap(heap.begin(), heap.end(), HeapAfter());
         ++next_id;
     }
+    // code length = depth below the root; a parent's id is larger than its children's, so one pass from the root down
+    std::vector<uint8_t> depth_of(static_cast<size_t>(next_id), 0);
+    for (int id = next_id - 2; id >= 0; --id) depth_of[static_cast<size_t>(id)] = static_cast<uint8_t>(depth_of[static_cast<size_t>(parent[id])] + 1);
+    // CanonicalSorter :27-35 orders by (length, symbol): leaves in symbol order (the pseudo-EOF is the largest symbol), then a
+    // stable counting sort by length
+    std::vector<int> leaf_of(table_size, -1);
+    for (int l = 0; l < eof_leaf; ++l) leaf_of[symbols[l]] = l;
+    std::vector<int> by_symbol;
+    by_symbol.reserve(static_cast<size_t>(leaves));
+    for (size_t v = 0; v < table_size; ++v)
+        if (leaf_of[v] >= 0) by_symbol.push_back(leaf_of[v]);
+    by_symbol.push_back(eof_leaf);
+    auto length_of_leaf = [&](int l) { return (n == 0 && l == eof_leaf) ? uint8_t(1) : depth_of[static_cast<size_t>(l)]; };   // :70 the lone pseudo-EOF gets length 1
+    size_t first_of_length[257] = {};
+    for (int l : by_symbol) ++first_of_length[static_cast<size_t>(length_of_leaf(l)) + 1];
+    for (int k = 1; k <= 256; ++k) first_of_length[k] += first_of_length[k - 1];
     std::vector<Entry> entries(static_cast<size_t>(leaves));
-    for (int l = 0; l < leaves; ++l) {
-        uint8_t len = (n == 0 && l == eof_leaf) ? 1 : 0;       // :70 the lone pseudo-EOF gets length 1
-        for (int p = parent[l]; p >= 0; p = parent[p]) ++len;
-        entries[l] = Entry{symbols[l], len, 0};
+    for (int l : by_symbol) {
+        const uint8_t len = length_of_leaf(l);
+        entries[first_of_length[len]++] = Entry{symbols[l], len, 0};
     }
-    std::sort(entries.begin(), entries.end(), [](const Entry& a, const Entry& b) {   // CanonicalSorter :27-35
-        return a.length == b.length ? a.symbol < b.symbol : a.length < b.length;
-    });
     const uint8_t max_length = std::max<uint8_t>(heap.front().depth, 1);
     t.max_length = max_length;
     out.put(max_length, 8);
