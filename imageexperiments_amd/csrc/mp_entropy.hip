@@ -20,10 +20,10 @@
 //     mirror   the per-stream records to host memory
 //   host: Huffman tables / Golomb parameter, bit offsets of every stream's payload in the container
 //   phase 2
-//     tables   scatter the (symbol -> code, length) entries into dense per-stream tables
+//     tables   the host's part of the per-stream records in; scatter the (symbol -> code, length) entries into dense per-stream tables
 //     count    code bits per block;  offsets  exclusive scan per stream, from the stream's bit offset
 //     write    the codes, MSB first, into the zeroed container (32-bit atomic ORs of byte-swapped words)
-//     clear    the table entries, for the next frame
+//     clear    the table entries, for the next frame; the per-stream records (bit counts) back to host memory
 // Integer work, HBM/L2-bound; 2 bytes per symbol and pass, ~10 M symbols per 16 Mpixel frame.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(kThreads) void ent_hist_kernel(const EntropyArgs a)
     if ((threadIdx.x & 63) == 63 && fresh) atomicAdd(&a.streams[j].distinct, fresh);
 }
 
-// where each stream's triples go in the list: exclusive scan of the distinct counts
+// where each stream's triples go in the list: exclusive scan of the distinct counts (and the write cursors, cleared)
 __global__ __launch_bounds__(kThreads) void ent_triple_offsets_kernel(const EntropyArgs a)
 {
     __shared__ unsigned distinct[kEntMaxStreams];
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(kThreads) void ent_compact_kernel(const EntropyArgs
 // The per-stream records and the totals, to their mirrors in host memory (and back, with the host's part filled in): kernels
 // write them across PCIe themselves -- a copy command would be a blit kernel or an SDMA packet queued somewhere else, and this
 // way the host needs nothing but the event behind the kernel.
-__global__ __launch_bounds__(kThreads) void ent_mirror_kernel(const EntropyArgs a, int to_host)
+__device__ __forceinline__ void mirror_streams(const EntropyArgs& a, int to_host)
 {
     const int words = (int)(sizeof(EntStream) / sizeof(unsigned)) * a.n_streams;
     const unsigned* src = reinterpret_cast<const unsigned*>(to_host ? a.streams : a.host_streams);
@@ -442,9 +442,17 @@ __global__ __launch_bounds__(kThreads) void ent_mirror_kernel(const EntropyArgs 
     if (to_host && threadIdx.x < 4) a.host_totals[threadIdx.x] = a.totals[threadIdx.x];
 }
 
+__global__ __launch_bounds__(kThreads) void ent_mirror_kernel(const EntropyArgs a, int to_host) { mirror_streams(a, to_host); }
+
 // ---- phase 2 ----
+// clear == 0: the host's records in (one extra workgroup, the last), (symbol -> code, length) entries into the dense tables;
+// clear != 0: the entries out of the tables again, the records back to the host (their bit counts are final by then)
 __global__ __launch_bounds__(kThreads) void ent_tables_kernel(const EntropyArgs a, int clear)
 {
+    if (blockIdx.x == gridDim.x - 1) {
+        mirror_streams(a, clear ? 1 : 0);
+        return;
+    }
     const unsigned e = blockIdx.x * kThreads + threadIdx.x;
     if (e >= a.n_entries) return;
     const unsigned key = a.entries[3 * (size_t)e];        // stream << 16 | symbol
@@ -596,13 +604,11 @@ int launch_entropy_phase2(const EntropyArgs& a, unsigned long long raw_symbols, 
     if (a.n_streams < 1 || a.n_streams > kEntMaxStreams) return (int)hipErrorInvalidValue;
     const unsigned blocks = (unsigned)entropy_max_blocks(raw_symbols, a.n_streams);
     const unsigned eblocks = (a.n_entries + kThreads - 1) / kThreads;
-    hipLaunchKernelGGL(ent_mirror_kernel, dim3(1), dim3(kThreads), 0, st, a, 0);
-    if (eblocks) hipLaunchKernelGGL(ent_tables_kernel, dim3(eblocks), dim3(kThreads), 0, st, a, 0);
+    hipLaunchKernelGGL(ent_tables_kernel, dim3(eblocks + 1), dim3(kThreads), 0, st, a, 0);
     hipLaunchKernelGGL(ent_code_kernel<false>, dim3(blocks), dim3(kThreads), 0, st, a);
     hipLaunchKernelGGL(ent_bit_offsets_kernel, dim3((unsigned)a.n_streams), dim3(64), 0, st, a);
     hipLaunchKernelGGL(ent_code_kernel<true>, dim3(blocks), dim3(kThreads), 0, st, a);
-    if (eblocks) hipLaunchKernelGGL(ent_tables_kernel, dim3(eblocks), dim3(kThreads), 0, st, a, 1);
-    hipLaunchKernelGGL(ent_mirror_kernel, dim3(1), dim3(kThreads), 0, st, a, 1);
+    hipLaunchKernelGGL(ent_tables_kernel, dim3(eblocks + 1), dim3(kThreads), 0, st, a, 1);
     return (int)hipGetLastError();
 }
 
