@@ -255,3 +255,18 @@ def test_symbol_streams_direct_and_planned_routes_equal_the_oracle(ia, oracle):
     assert direct == want
     planned = ia.assemble_symbol_streams(c["W"], c["H"], c["K"], c["bs"], q, c["counts"], c["as_coded"], by_plan=True)
     assert planned == want
+
+
+def test_container_jobs_refuse_misuse_without_touching_a_device(ia):
+    """mpc_container_job_*: a host-only context has no device (begin), a slot that has not begun has no tables to build, one
+    without tables nothing to collect, and slots are bounded -- status codes, no HIP call."""
+    ctx = ia.create_compression_context(8, 8, 3.5, device=-1)
+    with pytest.raises(ia.MpcError) as e:
+        ctx.container_job_begin(0, 1, 1, 64, 64)
+    assert e.value.status == ia.api.MPC_ERR_NO_DEVICE
+    for call in (lambda: ctx.container_job_tables(0), lambda: ctx.container_job_collect(0), lambda: ctx.container_job_tables(99),
+                 lambda: ctx.container_job_collect(-1)):
+        with pytest.raises(ia.MpcError) as e:
+            call()
+        assert e.value.status == ia.api.MPC_ERR_ARGUMENT
+    ctx.close()
