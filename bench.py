@@ -4,20 +4,29 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload raise|1080p|8k] [--quality Q] [--no-cpu]
 
 A *step* is one pass of the hot path over one batch of synthetic frames that are already resident in HBM:
-RGB in HBM -> tile encode (mp_pursuit_kernel, one launch) -> stream assembly on the device -> the live symbols
-to the host -> entropy stage -> container bytes (byte-identical to the reference's encodeImage; tests/test_gpu_golden_frames.py).
-N = 1: one frame per step; default workload = the north_star's: 4928x3264 synthetic RGB, K = 32, quality 3.5.  The K steps
-of the timed region go through the library's frame pipeline in one call (mpc_encode_images_device): the host entropy stage
-of step i overlaps the device work of step i + 1, as in any steady-state use.
-N > 1 (torch.distributed.run, one rank per GPU): weak scaling, N frames per step.  Every frame is row-striped over the N
-ranks (rank r encodes tile-row stripe r of every frame in one launch); the stripes' records then travel to the frame's owner
-(rank f owns frame f: batched point-to-point over RCCL/xGMI), which interleaves them into the reference's tile order and
-produces frame f's container.  No other collective: see DESIGN.md 7 for why the symbol-histogram all-reduce is not in it.
+RGB in HBM -> tile encode (mp_pursuit_kernel, one launch) -> stream assembly and the per-symbol work of the entropy stage on the
+device, one code table per stream on the host -> container bytes in host memory (byte-identical to the reference's encodeImage:
+after the timed region the containers are hashed against tests/golden/frames.json, `bytes_match_golden`).
+N = 1: one frame per step; default workload = the north_star's: 4928x3264 synthetic RGB, K = 32, quality 3.5; consecutive steps
+take DISTINCT frames (seeds 12345 + f, a cycle of up to 8).  The K steps of the timed region go through the library's frame
+pipeline in one call (mpc_encode_images_device): the host's table building of step i overlaps the device work of step i + 1, as
+in any steady-state use.  Beside `value` the line carries SURVEY 8(d)'s PCIe-inclusive figures, measured after the timed region:
+`host_to_bytes_Mpix_s` (pageable host RGB -> container bytes through mpc_encode_images, the same frames, pipelined) and
+`single_frame_ms` (one mpc_encode_image call).
+N > 1: one rank per GPU, launched by torch.distributed.run -- or by this script itself: `python bench.py --gpus N` without a
+launcher starts N child processes (fresh interpreters, before anything here touches a GPU) with RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_* set, relays rank 0's line and fails if any rank fails.  Weak scaling, N frames per step.  Every frame is row-striped over
+the N ranks (rank r encodes tile-row stripe r of every frame in one launch); the stripes' records then travel to the frame's owner
+(rank f owns frame f: batched point-to-point over RCCL/xGMI), which puts them into the reference's tile order and produces frame
+f's container.  No other collective: see DESIGN.md 7 for why the symbol-histogram all-reduce is not in it.
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -139,6 +148,52 @@ def stripe_bounds(tiles_y, n, r):
     return begin, begin + base + (1 if r < rem else 0)
 
 
+def golden_of(workload, q, seed):
+    """sha256 / size of the oracle's container for this synthetic frame (tests/golden/frames.json), or None."""
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "frames.json")) as f:
+            frames = json.load(f)
+    except Exception:
+        return None
+    W, H, K, _ = WORKLOADS[workload]
+    for rec in frames.values():
+        if (rec.get("kind") == "synthetic" and rec.get("flavour", "double") == "double" and rec["width"] == W and rec["height"] == H
+                and rec["K"] == K and abs(rec["quality"] - q) < 1e-9 and rec["seed"] == seed):
+            return rec["container_sha256"], rec["container_bytes"]
+    return None
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: N fresh child processes, one rank each, started BEFORE this process has touched a
+    GPU (it never does: it only relays).  Rank 0's stdout is passed on; a failing rank ends the others and the run."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
+                for o in live:
+                    procs[o].terminate()
+        time.sleep(0.05)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -154,7 +209,11 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo + --share-device rehearses the N>1 path on a one-GPU box")
     ap.add_argument("--share-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the untimed PCIe-inclusive legs (host_to_bytes_Mpix_s, single_frame_ms)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))            # nothing above has initialised a GPU
 
     import torch
     import torch.distributed as dist
@@ -164,8 +223,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    if args.gpus != world:
+        sys.exit(f"bench.py --gpus {args.gpus} inside a group of {world} ranks")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the hot path has no CPU fallback")
     if args.share_device:
@@ -185,11 +244,11 @@ def main():
     if args.fast:
         ctx.set_fast(True)
     tiles_x, tiles_y = (W + 7) // 8, (H + 7) // 8
-    frames = world                                           # weak scaling: N frames per step for N ranks
+    # N = 1: consecutive steps take distinct frames (a cycle of `frames`); N > 1: the N frames of a step (weak scaling)
+    frames = world if world > 1 else max(1, min(args.steps, 8))
     host_frames = np.stack([synth_frame(W, H, 12345 + f) for f in range(frames)])
     d_rgb = torch.from_numpy(host_frames).cuda()
     stream = torch.cuda.current_stream()
-    containers = []
 
     def fence():
         if world > 1:
@@ -197,10 +256,10 @@ def main():
         torch.cuda.synchronize()
 
     if world == 1:
-        ptr = d_rgb.data_ptr()
+        ptrs = [d_rgb[f].data_ptr() for f in range(frames)]
 
         def run(n):                                          # n steps = n frames through the pipeline, in one call
-            return ctx.encode_images_device([ptr] * n, W, H, views=True)     # the library's buffers as they are (no Python copy)
+            return ctx.encode_images_device([ptrs[i % frames] for i in range(n)], W, H, views=True)    # the library's buffers as they are
     else:
         striped = sharding.StripedEncoder(ctx, W, H, frames, world, rank, args.backend)
 
@@ -219,16 +278,60 @@ def main():
         elapsed = float(t.item())
     container_bytes = len(containers[-1])
 
+    # ---- untimed: the bytes of the timed region against the oracle's (tests/golden/frames.json) --------------------------------
+    # N = 1: container i is frame i % frames (seed 12345 + i % frames); N > 1: every container of this rank is frame `rank`
+    checked, matched = 0, 0
+    if not args.fast:
+        todo = {}
+        for i in range(len(containers)):
+            todo.setdefault(rank if world > 1 else i % frames, i)
+        for f, i in todo.items():
+            gold = golden_of(args.workload, q, 12345 + f)
+            if gold is None:
+                continue
+            checked += 1
+            blob = np.ascontiguousarray(containers[i])
+            matched += int(len(blob) == gold[1] and hashlib.sha256(blob.tobytes()).hexdigest() == gold[0])
+        # ... and every repetition of a frame equals its first container
+        for i in range(len(containers)):
+            first = todo[rank if world > 1 else i % frames]
+            if i != first and not np.array_equal(containers[i], containers[first]):
+                matched = -1
+                break
+    if world > 1:
+        v = torch.tensor([checked, matched if matched >= 0 else -10 ** 6], dtype=torch.int64, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(v)
+        checked, matched = int(v[0].item()), int(v[1].item())
+    bytes_match = None if checked == 0 else bool(matched == checked)
+
+    # ---- untimed: SURVEY 8(d)'s PCIe-inclusive figures: pageable host RGB -> container bytes ---------------------------------
+    host_to_bytes = single_ms = None
+    if world == 1 and not args.no_e2e:
+        seq = [host_frames[i % frames] for i in range(args.steps)]
+        ctx.encode_images(seq[:min(len(seq), 8)], views=True)                 # slots and staging allocated
+        t0 = time.perf_counter()
+        out = ctx.encode_images(seq, views=True)
+        host_to_bytes = W * H * len(seq) / (time.perf_counter() - t0) / 1e6
+        del out
+        ctx.encode_image(host_frames[0])
+        singles = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            ctx.encode_image(host_frames[0])
+            singles.append(time.perf_counter() - t0)
+        single_ms = sorted(singles)[len(singles) // 2] * 1e3
+
     # ---- untimed: the device stage alone, with HIP events around every launch of the dominant kernel -------------------------
     row_begin, row_end = stripe_bounds(tiles_y, world, rank)
-    tiles = frames * tiles_x * (row_end - row_begin)
+    stage_frames = world if world > 1 else 1
+    tiles = stage_frames * tiles_x * (row_end - row_begin)
     d_counts = torch.zeros((tiles, 3), dtype=torch.int16, device="cuda")
     d_choices = torch.zeros((tiles, 3, K), dtype=torch.int32, device="cuda")
     d_swept = torch.zeros((tiles, 3), dtype=torch.int32, device="cuda")
     dev_steps = max(3, min(args.steps, 10))
 
     def device_stage():
-        ctx.encode_batch_device(d_rgb.data_ptr(), frames, W * H * 3, W, H, W * 3, row_begin, row_end, d_counts.data_ptr(),
+        ctx.encode_batch_device(d_rgb.data_ptr(), stage_frames, W * H * 3, W, H, W * 3, row_begin, row_end, d_counts.data_ptr(),
                                 d_choices.data_ptr(), 0, d_swept.data_ptr(), stream=stream.cuda_stream)
     device_stage()
     torch.cuda.synchronize()
@@ -244,51 +347,62 @@ def main():
     swept_total = int(d_swept.to(torch.int64).sum().item())
 
     if rank == 0:
-        pixels_per_step = frames * W * H
+        pixels_per_step = frames * W * H if world > 1 else W * H
         value = pixels_per_step * args.steps / elapsed / 1e6
         launches_per_step = kern_launches // dev_steps
         flops_per_launch = mfma_instr * MFMA_FLOP / max(kern_launches, 1)
         avg_ms = kern_ms_total / max(kern_launches, 1)
         mfma_tflops = flops_per_launch / (avg_ms * 1e-3) / 1e12
-        # HBM traffic of the same kernel from separate rocprofv3 --pmc passes at this commit (tools/profile_round.sh)
-        traffic = traffic_src = None
-        hbm_gbs = None
-        pmc = os.path.join(ROOT, "profiles", f"r02_pmc_{args.workload}.json")
-        if args.quality is None and world == 1 and os.path.exists(pmc):
-            try:
-                rec = json.load(open(pmc))
-                traffic = rec.get("mp_pursuit_kernel", {}).get("hbm_bytes_per_launch")
-                traffic_src = "profiles/" + os.path.basename(pmc)
-                if traffic:
-                    hbm_gbs = traffic / (avg_ms * 1e-3) / 1e9
-            except Exception:
-                traffic = None
         mfma_frac = mfma_tflops / BF16_MFMA_PEAK_TFLOPS
-        hbm_frac = (hbm_gbs or 0.0) / HBM_PEAK_GBS
-        if hbm_frac > mfma_frac:
-            roof = {"bound": "hbm", "achieved": round(hbm_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_frac, 4)}
-        else:
-            roof = {"bound": "mfma", "achieved": round(mfma_tflops, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(mfma_frac, 4)}
-        roof.update({
+        # fabric traffic of the same kernel from separate rocprofv3 --pmc passes (tools/profile_round.sh), newest round first
+        traffic = traffic_src = fetch_raw = write_raw = None
+        wait_note = None
+        for tag in ("r03", "r02"):
+            pmc = os.path.join(ROOT, "profiles", f"{tag}_pmc_{args.workload}.json")
+            if args.quality is None and world == 1 and not args.fast and os.path.exists(pmc):
+                try:
+                    rec = json.load(open(pmc)).get("mp_pursuit_kernel", {})
+                    fetch_raw, write_raw = rec.get("raw_fetch_bytes_per_launch"), rec.get("write_bytes_per_launch")
+                    if fetch_raw and write_raw:
+                        traffic = fetch_raw + write_raw
+                        traffic_src = "profiles/" + os.path.basename(pmc)
+                        sq = os.path.join(ROOT, "profiles", f"{tag}_pmc_sq_{args.workload}.json")
+                        if os.path.exists(sq):
+                            k = json.load(open(sq))["per_kernel"]["mp_pursuit_kernel"]
+                            wait_note = (f"waves parked on memory {100 * k['SQ_WAIT_ANY_share_of_wave_cycles']:.0f} %, issue-stalled "
+                                         f"{100 * k['SQ_WAIT_INST_ANY_share_of_wave_cycles']:.0f} %, issuing "
+                                         f"{100 * k['SQ_ACTIVE_INST_ANY_share_of_wave_cycles']:.0f} % of their cycles (profiles/{os.path.basename(sq)})")
+                        break
+                except Exception:
+                    traffic = None
+        sec = avg_ms * 1e-3
+        roof = {
+            # The kernel is bound by per-step latency and instruction issue, not by a roof; the exactly measured utilisation is the
+            # matrix pipe's.  The contract's two roofs, both reported: frac = executed MFMA flops / dense bf16 peak; the memory side
+            # as fabric_frac_* (L2-side request bytes, Infinity-Cache hits included -- NOT HBM bytes).
+            "bound": "latency", "nearest_roof": "mfma",
+            "achieved": round(mfma_tflops, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(mfma_frac, 4),
             "traffic": traffic, "traffic_source": traffic_src,
+            "traffic_note": "FETCH_SIZE + WRITE_SIZE per launch of the same kernel, as counted, from two separate rocprofv3 --pmc passes of "
+                            "tools/quick_bench.py at the commit of that file (not this run): the L2's memory-side requests, "
+                            "Infinity-Cache hits included; the dictionary tables it re-reads (25 MB of operand tiles, Gram rows) live there",
+            "fabric_frac_raw": round(traffic / sec / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+            "fabric_frac_2x": round((2 * fetch_raw + write_raw) / sec / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+            "limited_by": wait_note,
             "kernel": "mp_pursuit_kernel", "kernel_avg_ms": round(avg_ms, 5), "kernel_launches_per_step": launches_per_step,
             "kernel_busy_ms_per_step": round(kern_busy_ms / dev_steps, 4),
             "executed_mfma_flops_per_launch": int(flops_per_launch),
-            "mfma_frac": round(mfma_frac, 4), "hbm_frac": round(hbm_frac, 4) if traffic else None,
             "tile_channel_steps_per_step": tc_steps // dev_steps,
             "simd_cycles_per_tile_channel_step_at_2p4GHz": round(dev_elapsed / max(tc_steps // dev_steps, 1) * 1024 * 2.4e9, 1),
             # SURVEY 8(d)'s algorithmic figure, kept for reference only: 64 * sizeof(double) per dictionary row the reference
             # correlates, over the device stage's time.  It is an algorithmic speed-up over a literal sweep, not a bandwidth:
             # the rows live in LDS as split-bf16 operands and only one or two per tile-channel-step are touched in double.
             "equivalent_sweep_GBps": round(64 * 8 * swept_total / dev_elapsed / 1e9, 1),
-            "note": "dominant kernel = mp_pursuit_kernel (one launch per step: "
-                    "kernel_avg_ms is its duration).  achieved = MFMA flops the "
-                    "kernel itself counted (every v_mfma_f32_16x16x32_bf16 executed, 16384 flop each) / its average launch duration "
-                    "(HIP events on the launch stream) against the dense bf16 peak; traffic = HBM bytes per launch from separate "
-                    "rocprofv3 --pmc passes at the same commit (2 x FETCH_SIZE + WRITE_SIZE: the guide's gfx950 correction).  "
-                    "frac = the larger of the two utilisations.  What bounds the kernel is per-step latency, not either roof "
-                    "(DESIGN.md 3, 9)"})
+            "note": "dominant kernel = mp_pursuit_kernel (one launch per step: kernel_avg_ms is its duration, HIP events on the launch "
+                    "stream).  achieved = MFMA flops the kernel itself counted (every v_mfma_f32_16x16x32_bf16 executed, 16384 flop each) "
+                    "/ that duration, against the dense bf16 peak.  fabric_frac_raw = traffic / duration / 8 TB/s; fabric_frac_2x applies "
+                    "the guide's gfx950 correction (2 x FETCH_SIZE, valid for 16 B/lane streams) and is an upper bound.  Neither roof "
+                    "binds: per-step latency does (DESIGN.md 3, 9)"}
         line = {
             "metric": "encode Mpixels/s at quality=3.5" if q == 3.5 else f"encode Mpixels/s at quality={q}",
             "value": round(value, 3),
@@ -302,25 +416,32 @@ def main():
             "vs_baseline": None,
             "dtype": "f32" if args.fast else "f64",
             "data": "synthetic",
-            "config": {"workload": f"{frames} x {W}x{H} synthetic RGB (mt19937 seed 12345+f), quality {q}, K={K} "
-                                   "atoms/tile-channel, 8x8 tiles" + (f", row-striped over {world} GPUs" if world > 1 else ""),
+            "config": {"workload": (f"{frames} x {W}x{H} synthetic RGB per step" if world > 1 else f"{W}x{H} synthetic RGB, {frames} distinct frames in turn")
+                                   + f" (mt19937 seed 12345+f), quality {q}, K={K} atoms/tile-channel, 8x8 tiles"
+                                   + (f", row-striped over {world} GPUs" if world > 1 else ""),
                        "stage": "frames resident in HBM -> tile encode, stream assembly and the per-symbol work of the entropy stage "
                                 "(run lengths, histograms, code writing) on the device; the host builds one code table per stream -> "
-                                "container bytes "
+                                "container bytes in host memory "
                                 + ("(the ...Fast / float flavour: PARITY UNPINNED against the reference's Eigen results; bit-identical to "
                                    "oracle/mpo_fast.c, PSNR / size equivalent to the double path)" if args.fast else
                                    "(byte-identical to the reference's encodeImage)")
                                 + ("; stripes' records exchanged between ranks so that rank f produces frame f's container" if world > 1 else
-                                   "; the steps of the timed region are pipelined (entropy stage of step i beside the device work of step i+1)"),
+                                   "; the steps of the timed region are pipelined (table building of step i beside the device work of step i+1)"),
                        "container_bytes": container_bytes, "bpp": round(8.0 * container_bytes / (W * H), 4)},
+            "bytes_match_golden": bytes_match,
+            "golden_containers_checked": checked,
+            "hbm_resident_Mpix_s": round(value, 3),
+            "host_to_bytes_Mpix_s": round(host_to_bytes, 3) if host_to_bytes else None,
+            "single_frame_ms": round(single_ms, 4) if single_ms else None,
             "device_stage_Mpix_s": round(pixels_per_step / world / dev_elapsed / 1e6, 3) if world > 1 else round(pixels_per_step / dev_elapsed / 1e6, 3),
             "device_stage_ms": round(dev_elapsed * 1e3, 4),
             "roofline": roof,
         }
         if not args.no_cpu and world == 1:
             line["cpu_baseline"] = cpu_baseline(W, H, K, q, host_frames[0], args.cpu_seconds)      # the double oracle, either way
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

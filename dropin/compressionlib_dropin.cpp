@@ -16,9 +16,9 @@
 // The dictionary crosses the reference's interface only as an opaque std::function ("dynamic dictionary").  Contexts made by
 // the factory here carry closures of a type this file recognises (std::function::target), which lead straight to the
 // mpc_context that holds the dictionary in HBM.  A foreign closure -- e.g. one made by the reference's own factory -- is
-// probed once (dyn(0, {}) is the base dictionary, dyn(1, {i}) appends DetailBasis[i]): if it is the standard
-// dictionary of that channel the same device path is used, otherwise the call fails like the reference fails, with a thrown
-// std::range_error*.
+// probed (dyn(0, {}) is the base dictionary, dyn(1, {i}) appends DetailBasis[i]; in full the first time a
+// std::function object is seen, a spot check on later calls: `identify`): if it is the standard dictionary of that channel the
+// same device path is used, otherwise the call fails like the reference fails, with a thrown std::range_error*.
 //
 // The Fast names (Eigen, float) run the float flavour of the device path (mpc_context_set_fast): the reference's Fast
 // statements in float on the dictionary rounded to float -- equivalent to the double path in PSNR and size, identical to
@@ -131,29 +131,66 @@ struct StandardDynamic {
     }
 };
 
-// Which channel of the standard dictionary does a closure stand for?  -1 = none.
+// Does `dyn` return the standard dictionary of channel `ch` for these base atoms?  dyn(0, {}) is the base dictionary,
+// dyn(1, {i}) appends DetailBasis[i].
+bool probe(const matching::DynamicDictionaryFunction& dyn, const HostDictionary& d, int ch, const int* atoms, int n_atoms, bool base_too) {
+    if (base_too) {
+        const std::vector<matching::BasisChoice> none;
+        const math::Matrix base = dyn(0, none);
+        if (base.Rows() != static_cast<size_t>(d.num_base) || base.Columns() != static_cast<size_t>(d.n)) return false;
+        if (std::memcmp(base.Data(), d.base.data(), d.base.size() * sizeof(double)) != 0) return false;
+    }
+    for (int k = 0; k < n_atoms; ++k) {
+        const int i = atoms[k];
+        std::vector<matching::BasisChoice> one(1);
+        one[0].deltaId = static_cast<unsigned short>(i);
+        one[0].intCoeff = 0;
+        const math::Matrix m = dyn(1, one);
+        if (m.Rows() != static_cast<size_t>(d.num_base + d.rows[i]) || m.Columns() != static_cast<size_t>(d.n) ||
+            std::memcmp(m.Data() + d.base.size(), d.detail[ch].data() + static_cast<size_t>(d.offset[i]) * d.n,
+                        static_cast<size_t>(d.rows[i]) * d.n * sizeof(double)) != 0)
+            return false;
+    }
+    return true;
+}
+
+// Which channel of the standard dictionary does a closure stand for?  -1 = none.  A closure of the factory here is recognised
+// by its type.  A foreign one is probed in full the first time it is seen (base + all 510 detail blocks against each channel);
+// the verdict is remembered for that std::function object (its address and target type), and a later call with the same object
+// re-checks only the base dictionary and three detail blocks -- an address can be reused by another closure, a whole different
+// dictionary behind the same object and type cannot hide from that.
 int identify(const matching::DynamicDictionaryFunction& dyn, size_t blockSize) {
     if (const StandardDynamic* mine = dyn.target<StandardDynamic>()) return mine->blockSize == blockSize ? mine->channel : -1;
     if (!dyn) return -1;
     const HostDictionary& d = host_dictionary(blockSize);
-    const std::vector<matching::BasisChoice> none;
-    const math::Matrix base = dyn(0, none);
-    if (base.Rows() != static_cast<size_t>(d.num_base) || base.Columns() != static_cast<size_t>(d.n)) return -1;
-    if (std::memcmp(base.Data(), d.base.data(), d.base.size() * sizeof(double)) != 0) return -1;
-    for (int ch = 0; ch < 3; ++ch) {
-        bool same = true;
-        for (int i = 0; i < d.num_base && same; ++i) {
-            std::vector<matching::BasisChoice> one(1);
-            one[0].deltaId = static_cast<unsigned short>(i);
-            one[0].intCoeff = 0;
-            const math::Matrix m = dyn(1, one);
-            same = m.Rows() == static_cast<size_t>(d.num_base + d.rows[i]) &&
-                   std::memcmp(m.Data() + d.base.size(), d.detail[ch].data() + static_cast<size_t>(d.offset[i]) * d.n,
-                               static_cast<size_t>(d.rows[i]) * d.n * sizeof(double)) == 0;
-        }
-        if (same) return ch;
+    struct Seen { const void* object; size_t type; size_t blockSize; int channel; };
+    static std::mutex lock;
+    static std::vector<Seen> seen;
+    const size_t type = dyn.target_type().hash_code();
+    {
+        std::lock_guard<std::mutex> hold(lock);
+        for (const Seen& s : seen)
+            if (s.object == &dyn && s.type == type && s.blockSize == blockSize) {
+                const int spot[3] = {0, d.num_base / 2, d.num_base - 1};
+                if (s.channel >= 0 && probe(dyn, d, s.channel, spot, 3, true)) return s.channel;
+                break;                                    // not what it was: probe in full again
+            }
     }
-    return -1;
+    std::vector<int> all(static_cast<size_t>(d.num_base));
+    for (int i = 0; i < d.num_base; ++i) all[static_cast<size_t>(i)] = i;
+    int channel = -1;
+    if (probe(dyn, d, 0, nullptr, 0, true))
+        for (int ch = 0; ch < 3 && channel < 0; ++ch)
+            if (probe(dyn, d, ch, all.data(), d.num_base, false)) channel = ch;
+    std::lock_guard<std::mutex> hold(lock);
+    bool updated = false;
+    for (Seen& s : seen)
+        if (s.object == &dyn && s.blockSize == blockSize) { s.type = type; s.channel = channel; updated = true; }
+    if (!updated) {
+        if (seen.size() >= 64) seen.erase(seen.begin());
+        seen.push_back(Seen{&dyn, type, blockSize, channel});
+    }
+    return channel;
 }
 
 void require_standard(const matching::DynamicDictionaryFunction& y, const matching::DynamicDictionaryFunction& u,

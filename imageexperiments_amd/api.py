@@ -112,6 +112,11 @@ def _bind_bitstream(L):
     L.mpc_encode_images.argtypes = [vp, C.POINTER(_u8p), C.c_int, C.c_int, C.c_int, _dp, C.POINTER(_u8p), C.POINTER(C.c_size_t)]
     L.mpc_encode_images_device.argtypes = [vp, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, _dp, C.POINTER(_u8p), C.POINTER(C.c_size_t)]
     L.mpc_records_to_container_device.argtypes = [vp, vp, vp, C.c_int, C.c_int, _dp, vp, C.POINTER(_u8p), C.POINTER(C.c_size_t)]
+    try:
+        L.mpc_interleave_stripe_device.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]
+    except AttributeError:
+        if not os.environ.get("MPCODEC_LIB"):             # an older build may be loaded for A/B timing only
+            raise
     L.mpc_encode_image_device.argtypes = [vp, vp, C.c_int, C.c_int, _dp, C.POINTER(_u8p), C.POINTER(C.c_size_t)]
     L.mpc_container_job_begin.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int, _dp, vp]
     L.mpc_container_job_tables.argtypes = [vp, C.c_int]
@@ -545,6 +550,12 @@ class CompressionContext:
 
     def encode_image_device(self, d_rgb, width, height, quant=None):
         return self.encode_images_device([d_rgb], width, height, quant)[0]
+
+    def interleave_stripe_device(self, d_part_counts, d_part_choices, width, height, tile_row_begin, tile_row_end, d_frame_counts,
+                                 d_frame_choices, stream=0):
+        """mpc_interleave_stripe_device: a row stripe's records (stripe order) -> their places in the whole frame's records."""
+        _check(self.L.mpc_interleave_stripe_device(self.h, d_part_counts, d_part_choices, width, height, tile_row_begin, tile_row_end,
+                                                   d_frame_counts, d_frame_choices, stream or None))
 
     def records_to_container_device(self, d_counts, d_choices, width, height, quant=None, stream=0):
         """mpc_records_to_container_device: whole-frame records in device memory -> container bytes."""

@@ -8,6 +8,7 @@
 #include <mutex>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <numeric>
 #include <thread>
 
@@ -910,10 +911,18 @@ public:
             ++generation_;
         }
         wake_.notify_all();
-        for (int i = next_.fetch_add(1); i < n; i = next_.fetch_add(1)) body(i);
-        std::unique_lock<std::mutex> hold(lock_);
-        done_.wait(hold, [&] { return pending_ == 0; });
-        body_ = nullptr;
+        work(body, n);
+        // Whatever a job threw, the generation is drained before `body` (the caller's stack) goes away; the first exception is
+        // then rethrown on the calling thread, where the C ABI's `guarded` turns it into a status.
+        std::exception_ptr first;
+        {
+            std::unique_lock<std::mutex> hold(lock_);
+            done_.wait(hold, [&] { return pending_ == 0; });
+            body_ = nullptr;
+            first = error_;
+            error_ = nullptr;
+        }
+        if (first) std::rethrow_exception(first);
     }
     ~WorkerPool() {
         {
@@ -926,6 +935,16 @@ public:
     }
 
 private:
+    // this thread's share of the jobs; a job that throws ends the call's remaining jobs (nobody starts another) and is remembered
+    void work(const std::function<void(int)>& body, int total) {
+        try {
+            for (int i = next_.fetch_add(1); i < total; i = next_.fetch_add(1)) body(i);
+        } catch (...) {
+            next_.store(total);
+            std::lock_guard<std::mutex> hold(lock_);
+            if (!error_) error_ = std::current_exception();
+        }
+    }
     void ensure(int count) {
         while (static_cast<int>(threads_.size()) < count) {
             const int id = static_cast<int>(threads_.size());
@@ -946,7 +965,7 @@ private:
                 body = body_;
                 total = total_;
             }
-            for (int i = next_.fetch_add(1); i < total; i = next_.fetch_add(1)) (*body)(i);
+            work(*body, total);
             {
                 std::lock_guard<std::mutex> hold(lock_);
                 if (--pending_ == 0) done_.notify_one();
@@ -961,6 +980,7 @@ private:
     int total_ = 0, pending_ = 0, active_limit_ = 0;
     unsigned long long generation_ = 0;
     bool stop_ = false;
+    std::exception_ptr error_;
 };
 
 template <class F>

@@ -125,7 +125,7 @@ struct DecodeParams {
 };
 int launch_decode(const DictDevice& dict, const DecodeParams& p, void* stream);
 
-// ---- persistent pursuit (mp_pursuit.hip): one launch per channel runs all K steps of every tile-channel of that channel ----
+// ---- persistent pursuit (mp_pursuit.hip): one launch runs all K steps of every tile-channel of a batch ----
 constexpr int kMaxPairs = 32;           // (tile-channel, unlocked block other than DetailBasis[0]) pairs a tile-channel can hold (< K)
 
 struct PursuitArgs {
@@ -144,9 +144,10 @@ struct PursuitArgs {
     const float* base32;
     const float* detail32[3];
     int fast;
-    // One launch covers all channels: workgroups [0, wg[0]) take channel 0's units, the next wg[1] channel 1's, then channel 2's
-    // (a workgroup's LDS holds DetailBasis[0] of ONE channel).  Vector mode: only `vec_channel` has workgroups.
-    int wg[3];
+    // One launch covers all channels with `workgroups` workgroups (one per CU).  Every WAVE works on one channel at a time: luma
+    // first, and once a channel's queue is dry the wave moves on to the next channel that has work (mp_pursuit.hip: channel
+    // switch), so a channel's last long tile-channels drain beside the next channel's work instead of beside idle SIMDs.
+    int workgroups;
     // input: tile mode (rgb) or vector mode (vec_in != nullptr: CalcMPDynamic on caller vectors of channel vec_channel)
     const uint8_t* rgb;
     int width, height;
@@ -154,19 +155,18 @@ struct PursuitArgs {
     int tile_row_begin, tile_rows, tiles_x;
     const double* vec_in;
     int vec_channel;
-    long long n_tc;                  // tile-channels per channel (tiles of the stripe x frames, or vectors)
-    int n_units;                     // ceil(n_tc / 16)
-    unsigned* queue;                 // [3] next unit of each channel (zero before the launch)
-    // per-wave scratch for the pairs, per channel (sizes: pursuit_scratch_*)
-    float* pair_p[3];
-    unsigned* pair_meta[3];
-    float* pair_e[3];
+    long long n_tc[3];               // tile-channels of each channel (tiles of the stripe x frames; vector mode: only vec_channel's is not 0)
+    unsigned* queue;                 // [3] next tile-channel of each channel (zero before the launch)
+    // per-wave scratch for the pairs (sizes: pursuit_scratch_*): a wave's own, whatever channel it works on
+    float* pair_p;
+    unsigned* pair_meta;
+    float* pair_e;
     Outputs out;
     unsigned long long* stats;       // [2] += executed MFMA instructions, tile-channel-steps (one atomic per wave at exit); may be null
     unsigned long long* debug;       // diagnostic builds (-DMPC_STAMPS) only: 24 phase-cycle / event counters; else null
 };
 
-int launch_pursuit(const PursuitArgs& args, void* stream);       // grid = wg[0] + wg[1] + wg[2] workgroups
+int launch_pursuit(const PursuitArgs& args, void* stream);       // grid = args.workgroups
 size_t pursuit_scratch_floats(int workgroups);
 size_t pursuit_scratch_meta(int workgroups);
 size_t pursuit_scratch_bounds(int workgroups);
@@ -189,6 +189,9 @@ struct StreamArgs {
 };
 size_t stream_workspace_words(long long tiles, int K);
 int launch_stream_assembly(const StreamArgs& a, void* stream);
+// records of the tile rows [row_begin, row_begin + rows) in stripe order -> their places in the whole frame's records
+int launch_interleave_stripe(const uint16_t* part_counts, const uint32_t* part_choices, int tiles_x, int tiles_y, int row_begin, int rows,
+                             int K, uint16_t* frame_counts, uint32_t* frame_choices, void* stream);
 
 // ---- device-side entropy stage (mp_entropy.hip): everything that touches every symbol of the 1 + 6K streams ----
 constexpr int kEntBlock = 4096;         // symbols per scan block

@@ -290,41 +290,64 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
     unsigned long long stamp_acc[24];
     for (int i = 0; i < 24; ++i) stamp_acc[i] = 0;
     unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
+    const unsigned long long wg_begin = __builtin_amdgcn_s_memrealtime();      // 100 MHz: workgroup residency timeline
 #endif
     __shared__ uint4 s_tiles[kTilesLds * 256];                      // [tile][operand q][lane], 4 KiB per tile
     __shared__ int s_rows[512], s_rowoff[512];                      // block_rows / block_row_off
     __shared__ unsigned s_touch[64 * kWaves];                       // landing zone of the cache-touch loads (never read)
-    __shared__ double s_quant[kMaxDeviceK];                         // the channel's quantisers (steps differ per lane)
-    // this workgroup's channel and its index among that channel's workgroups
-    const int ch = (int)blockIdx.x < a.wg[0] ? 0 : ((int)blockIdx.x < a.wg[0] + a.wg[1] ? 1 : 2);
-    const int wg_local = (int)blockIdx.x - (ch == 0 ? 0 : (ch == 1 ? a.wg[0] : a.wg[0] + a.wg[1]));
+    __shared__ double s_quant[3][kMaxDeviceK];                      // the quantisers (steps differ per lane, channels per wave)
+    // Tiles 0 .. 31 (base rows) serve every channel; tiles 32 .. 35 hold DetailBasis[0] of ONE channel, the workgroup's "home".
+    // A wave whose channel is not the home reads those four tiles from memory instead (16 KiB per step, L2-resident).  The last
+    // wave to leave the home channel makes its next channel the home (see the channel switch below).
+    __shared__ int s_home;                                          // home channel; -1 while tiles 32 .. 35 are being replaced
+    __shared__ int s_on[3];                                         // waves of this workgroup at work on each channel
+    const int ch_first = a.n_tc[0] > 0 ? 0 : (a.n_tc[1] > 0 ? 1 : 2);
     const T* const base_rows = reinterpret_cast<const T*>(kFast ? static_cast<const void*>(a.base32) : static_cast<const void*>(a.base));
-    const T* const detail = reinterpret_cast<const T*>(kFast ? static_cast<const void*>(ch == 0 ? a.detail32[0] : (ch == 1 ? a.detail32[1] : a.detail32[2]))
-                                                             : static_cast<const void*>(ch == 0 ? a.detail[0] : (ch == 1 ? a.detail[1] : a.detail[2])));
-    const uint16_t* const block_tiles = ch == 0 ? a.block_tiles[0] : (ch == 1 ? a.block_tiles[1] : a.block_tiles[2]);
-    const float* const gram = ch == 0 ? a.gram[0] : (ch == 1 ? a.gram[1] : a.gram[2]);
-    const double* const quant = a.quant + ch * a.K;
-    unsigned* const queue = a.queue + ch;
     {
+        const uint16_t* const blk0 = ch_first == 0 ? a.block_tiles[0] : (ch_first == 1 ? a.block_tiles[1] : a.block_tiles[2]);
         const uint4* src_base = reinterpret_cast<const uint4*>(a.base_tiles);
-        const uint4* src_blk0 = reinterpret_cast<const uint4*>(block_tiles);        // block 0 = the first four tiles
+        const uint4* src_blk0 = reinterpret_cast<const uint4*>(blk0);               // block 0 = the first four tiles
         for (int i = threadIdx.x; i < kTilesLds * 256; i += 64 * kWaves)
             s_tiles[i] = i < kBaseFilterTiles * 256 ? src_base[i] : src_blk0[i - kBaseFilterTiles * 256];
         for (int i = threadIdx.x; i < 512; i += 64 * kWaves) {
             s_rows[i] = i < a.num_base ? a.block_rows[i] : 0;
             s_rowoff[i] = i < a.num_base ? a.block_row_off[i] : 0;
         }
-        if (threadIdx.x < kMaxDeviceK) s_quant[threadIdx.x] = (int)threadIdx.x < a.K ? quant[threadIdx.x] : 1.0;
+        for (int i = threadIdx.x; i < 3 * kMaxDeviceK; i += 64 * kWaves)
+            s_quant[i / kMaxDeviceK][i % kMaxDeviceK] = (i % kMaxDeviceK) < a.K ? a.quant[(i / kMaxDeviceK) * a.K + i % kMaxDeviceK] : 1.0;
+        if (threadIdx.x == 0) {
+            s_home = ch_first;
+            s_on[0] = s_on[1] = s_on[2] = 0;
+            s_on[ch_first] = kWaves;
+        }
     }
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int slot = lane & 15, h = lane >> 4;
     const int pix0 = 16 * pos_of(h);                                // first of this lane's 16 consecutive pixels
-    const long long wave_global = (long long)wg_local * kWaves + wave;
-    float* const my_p = (ch == 0 ? a.pair_p[0] : (ch == 1 ? a.pair_p[1] : a.pair_p[2])) + wave_global * (kGroups * 16 * kMaxPairs * 64);
-    unsigned* const my_meta = (ch == 0 ? a.pair_meta[0] : (ch == 1 ? a.pair_meta[1] : a.pair_meta[2])) + wave_global * (kGroups * 16 * kMaxPairs * 2);
-    float* const my_e = (ch == 0 ? a.pair_e[0] : (ch == 1 ? a.pair_e[1] : a.pair_e[2])) + wave_global * (kGroups * 16 * kMaxPairs);
+    // the wave's channel and everything that depends on it (wave-uniform: scalar registers)
+    int ch = ch_first;
+    const T* detail = nullptr;
+    const uint16_t* block_tiles = nullptr;
+    const float* gram = nullptr;
+    unsigned* queue = nullptr;
+    long long n_tc = 0;
+    auto bind_channel = [&](int c) {
+        c = __builtin_amdgcn_readfirstlane(c);
+        ch = c;
+        detail = reinterpret_cast<const T*>(kFast ? static_cast<const void*>(c == 0 ? a.detail32[0] : (c == 1 ? a.detail32[1] : a.detail32[2]))
+                                                  : static_cast<const void*>(c == 0 ? a.detail[0] : (c == 1 ? a.detail[1] : a.detail[2])));
+        block_tiles = c == 0 ? a.block_tiles[0] : (c == 1 ? a.block_tiles[1] : a.block_tiles[2]);
+        gram = c == 0 ? a.gram[0] : (c == 1 ? a.gram[1] : a.gram[2]);
+        queue = a.queue + c;
+        n_tc = c == 0 ? a.n_tc[0] : (c == 1 ? a.n_tc[1] : a.n_tc[2]);
+    };
+    bind_channel(ch_first);
+    const long long wave_global = (long long)blockIdx.x * kWaves + wave;
+    float* const my_p = a.pair_p + wave_global * (kGroups * 16 * kMaxPairs * 64);
+    unsigned* const my_meta = a.pair_meta + wave_global * (kGroups * 16 * kMaxPairs * 2);
+    float* const my_e = a.pair_e + wave_global * (kGroups * 16 * kMaxPairs);
     unsigned* const my_touch = s_touch + 64 * wave;
     const int K = a.K;
 
@@ -360,10 +383,18 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
 #pragma unroll
         for (int q = 0; q < 4; ++q) dst[q] = s_tiles[t * 256 + q * 64 + lane];
     };
+    // tile t of DetailBasis[0] of the wave's channel from memory (a wave away from the workgroup's home channel)
+    auto far_tile = [&](uint4 (&dst)[4], int t) {
+        const uint4* tiles = reinterpret_cast<const uint4*>(block_tiles) + lane;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dst[q] = tiles[t * 256 + q * 64];
+    };
 
     for (;;) {
         // ---- (1) refill: slots whose tile-channel has ended take the next tile-channels from the queue, kRefillAt or more at
         //      a time (one atomic per refill; a wave whose slots are all free refills at once)
+        bool any_unit = false;
+        for (;;) {
         static_for<kGroups>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
             if (queue_empty) return;
@@ -373,9 +404,9 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
             int first = 0;
             if (lane == 0) first = (int)atomicAdd(queue, (unsigned)n_free);
             first = __builtin_amdgcn_readfirstlane(first);
-            if ((long long)first + n_free >= a.n_tc) queue_empty = true;
+            if ((long long)first + n_free >= n_tc) queue_empty = true;
             const long long t = (long long)first + __popc(free_slots & ((1u << slot) - 1u));
-            const bool take = !tc[g].live && t < a.n_tc;
+            const bool take = !tc[g].live && t < n_tc;
             if (!__ballot(take)) return;
             unit[g] = 0;
             TileChannel s;
@@ -418,10 +449,37 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
                 tc[g] = s;
             }
         });
-        bool any_unit = false;
 #pragma unroll
         for (int g = 0; g < kGroups; ++g) any_unit = any_unit || unit[g] >= 0;
+        if (any_unit || !queue_empty) break;
+        // ---- channel switch: the wave holds nothing and its channel's queue is dry -> the next channel that has work.  The
+        //      workgroup's LDS holds DetailBasis[0] of its home channel only: the last wave to leave the home channel (no wave
+        //      reads tiles 32 .. 35 any more) copies its next channel's four tiles there and declares it the new home; until then,
+        //      and for waves on yet another channel, those tiles come from memory (`home` below).
+        int next = ch + 1;
+        while (next < 3 && (next == 1 ? a.n_tc[1] : a.n_tc[2]) == 0) ++next;
+        if (next >= 3) break;
+        int was_on = 0;
+        if (lane == 0) {
+            __hip_atomic_fetch_add(&s_on[next], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            was_on = __hip_atomic_fetch_add(&s_on[ch], -1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        was_on = __builtin_amdgcn_readfirstlane(was_on);
+        const int old_home = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&s_home, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if (was_on == 1 && old_home == ch) {
+            if (lane == 0) __hip_atomic_store(&s_home, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint4* src = reinterpret_cast<const uint4*>(next == 1 ? a.block_tiles[1] : a.block_tiles[2]);
+#pragma unroll 4
+            for (int i = lane; i < kBlockFilterTiles * 256; i += 64) s_tiles[kBaseFilterTiles * 256 + i] = src[i];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) __hip_atomic_store(&s_home, next, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        bind_channel(next);
+        queue_empty = false;
+        }
         if (!any_unit) break;
+        // does this workgroup's LDS hold DetailBasis[0] of this wave's channel?  (it cannot change while the wave has live slots)
+        const bool home = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&s_home, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) == ch;
         static_for<kGroups>([&](auto gc) { n_steps += (unsigned)__popcll(__ballot(unit[decltype(gc)::value] >= 0 && tc[decltype(gc)::value].live && h == 0)); });
         STAMP(0)
         COUNT(12, 1)
@@ -653,13 +711,25 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
             for (int g = 0; g < kGroups; ++g) acc[g] = tile_mfma(tbuf, bh[g], bl[g]);
             track(tb, prev, 4 * (kBaseFilterTiles - 2));
             track(tb, acc, 4 * (kBaseFilterTiles - 1));
-            if (any0) {
+            if (any0 && home) {
 #pragma unroll 1
                 for (int t = 0; t < kBlockFilterTiles; ++t) {
                     lds_tile(ta, kBaseFilterTiles + t);
 #pragma unroll
                     for (int g = 0; g < kGroups; ++g) acc[g] = tile_mfma(ta, bh[g], bl[g]);
                     track(td, acc, 4 * t);
+                }
+            } else if (any0) {                                      // two tiles in flight, like a new pair's
+#pragma unroll
+                for (int t = 0; t < kBlockFilterTiles; t += 2) {
+                    far_tile(ta, t);
+                    far_tile(tbuf, t + 1);
+#pragma unroll
+                    for (int g = 0; g < kGroups; ++g) acc[g] = tile_mfma(ta, bh[g], bl[g]);
+                    track(td, acc, 4 * t);
+#pragma unroll
+                    for (int g = 0; g < kGroups; ++g) acc[g] = tile_mfma(tbuf, bh[g], bl[g]);
+                    track(td, acc, 4 * (t + 1));
                 }
             }
         }
@@ -720,10 +790,14 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
             uint4 cur[4], nxt[4];
             lds_tile(cur, 0);
             const int last = any0 ? kTilesLds : kBaseFilterTiles;
+            auto any_tile = [&](uint4 (&dst)[4], int t) {
+                if (t < kBaseFilterTiles || home) lds_tile(dst, t);
+                else far_tile(dst, t - kBaseFilterTiles);
+            };
             static_for<kGroups>([&](auto gc) { n_mfma += pass2[decltype(gc)::value] ? 6 * last : 0; });
 #pragma unroll 1
             for (int t = 0; t < last; ++t) {
-                lds_tile(nxt, t + 1 < last ? t + 1 : t);
+                any_tile(nxt, t + 1 < last ? t + 1 : t);
                 const bool is_base = t < kBaseFilterTiles;
                 const int row0 = (is_base ? t : t - kBaseFilterTiles) * 16 + 4 * h;
                 const int limit = is_base ? a.num_base : a.rows0;
@@ -900,7 +974,7 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
                 const int id = best_idx[g];
                 const unsigned delta = s.step > 0 ? (((unsigned)(id - s.prev_id) << 1) ^ (unsigned)((id - s.prev_id) >> 31)) : (unsigned)id;
                 s.prev_id = id;
-                const T qstep = (T)s_quant[s.step];             // Fast: Eigen::VectorXf quantization
+                const T qstep = (T)s_quant[ch][s.step];             // Fast: Eigen::VectorXf quantization
                 const T ratio = best_val[g] / qstep;
                 const int q = kFast ? (int)__builtin_roundf((float)ratio) : (int)__builtin_round((double)ratio);
                 const unsigned zz = ((unsigned)q << 1) ^ (unsigned)(q >> 31);
@@ -979,7 +1053,7 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
             while (pend) {                                          // a new pair's 16 KiB of filter tiles: 128 lines, two per lane
                 const int src = __builtin_ctzll(pend);
                 pend &= pend - 1;
-                const int blk = __builtin_amdgcn_readlane((int)(s.packed(s.fresh < 4 ? s.fresh : 0) & 511u), src);
+                const int blk = __builtin_amdgcn_readlane((int)(s.packed(s.fresh >= 0 && s.fresh < 4 ? s.fresh : 0) & 511u), src);
                 const uint16_t* tiles = block_tiles + (long long)blk * (kBlockFilterTiles * 2048) + 64 * lane;
                 __builtin_amdgcn_global_load_lds(tiles, my_touch, 4, 0, 0);
                 __builtin_amdgcn_global_load_lds(tiles + 4096, my_touch, 4, 0, 0);
@@ -997,6 +1071,10 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
 #ifdef MPC_STAMPS
     if (lane == 0 && a.debug)
         for (int i = 0; i < 24; ++i) atomicAdd(a.debug + i, stamp_acc[i]);
+    if (lane == 0 && a.debug && blockIdx.x < 1024) {                           // [24 + 2 b] = first wave in, [25 + 2 b] = last wave out
+        atomicMin(a.debug + 24 + 2 * blockIdx.x, wg_begin);
+        atomicMax(a.debug + 25 + 2 * blockIdx.x, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    }
 #endif
 }
 
@@ -1064,7 +1142,7 @@ int pursuit_units_per_workgroup() { return kWavesDouble * kGroups; }
 
 int launch_pursuit(const PursuitArgs& args, void* stream)
 {
-    const int workgroups = args.wg[0] + args.wg[1] + args.wg[2];
+    const int workgroups = args.workgroups;
     if (workgroups < 1) return (int)hipErrorInvalidValue;
     if (args.fast)
         hipLaunchKernelGGL((mp_pursuit_kernel<float, kWavesFloat>), dim3((unsigned)workgroups), dim3(64 * kWavesFloat), 0, static_cast<hipStream_t>(stream), args);

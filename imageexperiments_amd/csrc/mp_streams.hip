@@ -154,6 +154,37 @@ __global__ __launch_bounds__(256) void mp_stream_dc_kernel(const StreamArgs a)
     }
 }
 
+// A row stripe's records (tile t = tx * rows + ty_local, the order mpc_encode_tiles_device writes a stripe in) copied to their
+// places in a whole frame's records (t = tx * tiles_y + row_begin + ty_local): the step between the stripe exchange of the
+// multi-GPU path and the stream assembly, which reads whole frames in the reference's tile order (CompressedImage.cpp:535-537).
+// Both sides are runs of rows * 3K words per tile column: coalesced reads and writes.
+__global__ __launch_bounds__(256) void mp_interleave_stripe_kernel(const uint16_t* __restrict__ part_counts, const uint32_t* __restrict__ part_choices,
+                                                                   int tiles_x, int tiles_y, int row_begin, int rows, int K,
+                                                                   uint16_t* __restrict__ frame_counts, uint32_t* __restrict__ frame_choices)
+{
+    const long long words_per_col = (long long)rows * 3 * K, n_words = words_per_col * tiles_x;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_words; i += (long long)gridDim.x * 256) {
+        const long long tx = i / words_per_col, w = i - tx * words_per_col;
+        frame_choices[(tx * tiles_y + row_begin) * 3 * K + w] = part_choices[i];
+    }
+    const long long halves_per_col = (long long)rows * 3, n_halves = halves_per_col * tiles_x;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_halves; i += (long long)gridDim.x * 256) {
+        const long long tx = i / halves_per_col, w = i - tx * halves_per_col;
+        frame_counts[(tx * tiles_y + row_begin) * 3 + w] = part_counts[i];
+    }
+}
+
+int launch_interleave_stripe(const uint16_t* part_counts, const uint32_t* part_choices, int tiles_x, int tiles_y, int row_begin, int rows,
+                             int K, uint16_t* frame_counts, uint32_t* frame_choices, void* stream_)
+{
+    if (tiles_x < 1 || rows < 1 || row_begin < 0 || row_begin + rows > tiles_y || K < 1 || K > kMaxDeviceK) return (int)hipErrorInvalidValue;
+    const long long n_words = (long long)rows * 3 * K * tiles_x;
+    const unsigned blocks = (unsigned)((n_words + 255) / 256 < 4096 ? (n_words + 255) / 256 : 4096);
+    hipLaunchKernelGGL(mp_interleave_stripe_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream_), part_counts, part_choices,
+                       tiles_x, tiles_y, row_begin, rows, K, frame_counts, frame_choices);
+    return (int)hipGetLastError();
+}
+
 size_t stream_workspace_words(long long tiles, int K)
 {
     const long long blocks = (tiles + kBlockTiles - 1) / kBlockTiles;

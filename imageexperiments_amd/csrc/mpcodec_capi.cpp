@@ -91,9 +91,9 @@ struct DeviceDict {
     std::mutex launch_lock;           // one enqueue sequence at a time
     hipEvent_t done[1] = {};          // recorded behind every launch: the next one (any stream) waits for it
     int workgroups = 0;               // scratch is sized for this many workgroups per launch
-    float* pair_p[3] = {};
-    unsigned* pair_meta[3] = {};
-    float* pair_e[3] = {};
+    float* pair_p = nullptr;          // per-wave scratch of the persistent kernel (pairs: approximations, meta, bounds)
+    unsigned* pair_meta = nullptr;
+    float* pair_e = nullptr;
     unsigned* queues = nullptr;       // [3]
     unsigned long long* stats = nullptr;   // [2]: MFMA instructions, tile-channel-steps executed by the persistent kernel since the last reset
     ~DeviceDict() {
@@ -104,9 +104,7 @@ struct DeviceDict {
         (void)hipFree(d_base32); (void)hipFree(d_detail32);
         (void)hipFree(d_base_f32); (void)hipFree(d_detail_f32); (void)hipFree(d_base_t1); (void)hipFree(d_detail_t1);
         (void)hipFree(d_shadow); (void)hipFree(d_gram); (void)hipFree(queues); (void)hipFree(stats);
-        for (int ch = 0; ch < 3; ++ch) {
-            (void)hipFree(pair_p[ch]); (void)hipFree(pair_meta[ch]); (void)hipFree(pair_e[ch]);
-        }
+        (void)hipFree(pair_p); (void)hipFree(pair_meta); (void)hipFree(pair_e);
         if (done[0]) (void)hipEventDestroy(done[0]);
     }
 };
@@ -176,11 +174,9 @@ hipError_t acquire_device_dict(int device, const mpc::Dictionary& dict, std::sha
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d->queues), 64);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d->stats), 2 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(d->stats, 0, 2 * sizeof(unsigned long long));
-    for (int ch = 0; ch < 3 && e == hipSuccess; ++ch) {
-        e = hipMalloc(reinterpret_cast<void**>(&d->pair_p[ch]), sizeof(float) * mpc::pursuit_scratch_floats(d->workgroups));
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d->pair_meta[ch]), sizeof(unsigned) * mpc::pursuit_scratch_meta(d->workgroups));
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d->pair_e[ch]), sizeof(float) * mpc::pursuit_scratch_bounds(d->workgroups));
-    }
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d->pair_p), sizeof(float) * mpc::pursuit_scratch_floats(d->workgroups));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d->pair_meta), sizeof(unsigned) * mpc::pursuit_scratch_meta(d->workgroups));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d->pair_e), sizeof(float) * mpc::pursuit_scratch_bounds(d->workgroups));
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) return e;
     if (device < 64) g_dicts[device] = d;
@@ -373,14 +369,12 @@ mpc_status run_persistent(mpc_context* c, const mpc::FrameInput& in, const mpc::
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool vec = in.vec_in != nullptr;
     const long long n_tc = vec ? total_tc : total_tc / 3;
-    const long long n_units = (n_tc + 15) / 16;
-    if (n_units >= (1LL << 31)) return fail(MPC_ERR_ARGUMENT, "batch too large");
+    const long long n_units = (n_tc + 15) / 16 * (vec ? 1 : 3);         // groups of 16 tile-channels, all channels
+    if (n_tc >= (1LL << 31)) return fail(MPC_ERR_ARGUMENT, "batch too large");
+    // One workgroup fits a CU (its LDS holds the dictionary); its waves start on luma and move on to the chroma channels as the
+    // queues run dry (mp_pursuit.hip: channel switch), so a small frame spreads over the channels by itself.
     const int per_wg = mpc::pursuit_units_per_workgroup();
     int workgroups = static_cast<int>(std::min<long long>((n_units + per_wg - 1) / per_wg, d.workgroups));
-    // One workgroup fits a CU (its LDS holds the dictionary).  The luma workgroups come first in the grid and get the CUs
-    // first; chroma workgroups take over as they retire.  A small frame (less than three rounds of the machine in all) gets a
-    // third of the CUs per channel instead, so that all three run side by side from the start.
-    if (!vec && 3 * n_units < 3LL * d.workgroups * per_wg) workgroups = std::min(workgroups, std::max(1, d.workgroups / 3));
     const int forced = env_int("MPC_WORKGROUPS", 0);
     if (forced > 0) workgroups = std::min(forced, d.workgroups);
     std::lock_guard<std::mutex> hold(d.launch_lock);
@@ -397,11 +391,12 @@ mpc_status run_persistent(mpc_context* c, const mpc::FrameInput& in, const mpc::
         a.detail32[ch] = d.d_detail32 + static_cast<size_t>(ch) * d.detail_rows * mpc::kTileN;
         a.block_tiles[ch] = d.d_detail_t1 + static_cast<size_t>(ch) * d.num_base * mpc::kBlockFilterTiles * mpc::kFilterTileHalves;
         a.gram[ch] = d.d_gram + static_cast<size_t>(ch) * n_sel * stride;
-        a.pair_p[ch] = d.pair_p[ch];
-        a.pair_meta[ch] = d.pair_meta[ch];
-        a.pair_e[ch] = d.pair_e[ch];
-        a.wg[ch] = vec ? (ch == in.vec_channel ? workgroups : 0) : workgroups;
+        a.n_tc[ch] = vec ? (ch == in.vec_channel ? n_tc : 0) : n_tc;
     }
+    a.pair_p = d.pair_p;
+    a.pair_meta = d.pair_meta;
+    a.pair_e = d.pair_e;
+    a.workgroups = workgroups;
     a.gram_stride = stride;
     a.block_rows = d.d_rows;
     a.block_row_off = d.d_rowoff;
@@ -419,8 +414,6 @@ mpc_status run_persistent(mpc_context* c, const mpc::FrameInput& in, const mpc::
     a.tiles_x = in.tiles_x;
     a.vec_in = in.vec_in;
     a.vec_channel = in.vec_channel;
-    a.n_tc = n_tc;
-    a.n_units = static_cast<int>(n_units);
     a.queue = d.queues;
     a.out = out;
     a.stats = d.stats;
@@ -437,9 +430,15 @@ mpc_status run_persistent(mpc_context* c, const mpc::FrameInput& in, const mpc::
         HIP_TRY(hipEventRecord(ev[0], s));
     }
 #ifdef MPC_STAMPS
+    constexpr int kDebugWords = 24 + 2 * 1024;
     static unsigned long long* d_debug = nullptr;
-    if (!d_debug) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_debug), 24 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemsetAsync(d_debug, 0, 24 * sizeof(unsigned long long), s));
+    if (!d_debug) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_debug), kDebugWords * sizeof(unsigned long long)));
+    {
+        std::vector<unsigned long long> init(kDebugWords, 0ULL);
+        for (int b = 0; b < 1024; ++b) init[24 + 2 * b] = ~0ULL;
+        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipMemcpy(d_debug, init.data(), kDebugWords * sizeof(unsigned long long), hipMemcpyHostToDevice));
+    }
     a.debug = d_debug;
 #endif
     const int err = mpc::launch_pursuit(a, s);
@@ -448,16 +447,38 @@ mpc_status run_persistent(mpc_context* c, const mpc::FrameInput& in, const mpc::
     HIP_TRY(hipEventRecord(d.done[0], s));
 #ifdef MPC_STAMPS
     {
-        unsigned long long hst[24];
+        std::vector<unsigned long long> all(kDebugWords);
         HIP_TRY(hipStreamSynchronize(s));
-        HIP_TRY(hipMemcpy(hst, d_debug, sizeof hst, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(all.data(), d_debug, kDebugWords * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        const unsigned long long* hst = all.data();
         unsigned long long tot = 0;
         for (int i = 0; i < 12; ++i) tot += hst[i];
-        std::fprintf(stderr, "[stamps wg%d x3] wave-steps %llu live-lanes/step %.1f pass2-groups %llu rounds %llu exhaustive %llu | cycles/wave-step:",
+        std::fprintf(stderr, "[stamps wg%d] wave-steps %llu live-lanes/step %.1f pass2-groups %llu rounds %llu exhaustive %llu | cycles/wave-step:",
                      workgroups, hst[12], hst[12] ? (double)hst[16] / hst[12] / 4.0 : 0.0, hst[13], hst[14], hst[15]);
         for (int i = 0; i < 12; ++i) std::fprintf(stderr, " %d:%.0f", i, hst[12] ? (double)hst[i] / hst[12] : 0.0);
         std::fprintf(stderr, " total %.0f | pair rounds/step %.2f slots/round %.2f new pairs/step %.2f\n", hst[12] ? (double)tot / hst[12] : 0.0,
                      hst[12] ? (double)hst[17] / hst[12] : 0.0, hst[17] ? (double)hst[18] / hst[17] : 0.0, hst[12] ? (double)hst[19] / hst[12] : 0.0);
+        // workgroup residency: how many workgroups are on the machine over the launch (20 slices), and per channel when its
+        // first / last workgroup came and went (microseconds from the first workgroup's start; 100 MHz counter)
+        const int grid = a.workgroups;
+        unsigned long long t0 = ~0ULL, t1 = 0;
+        for (int b = 0; b < grid && b < 1024; ++b) { t0 = std::min(t0, all[24 + 2 * b]); t1 = std::max(t1, all[25 + 2 * b]); }
+        if (t1 > t0) {
+            const double span = (double)(t1 - t0);
+            double busy = 0.0;
+            int slices[20] = {};
+            for (int b = 0; b < grid && b < 1024; ++b) {
+                busy += (double)(all[25 + 2 * b] - all[24 + 2 * b]);
+                for (int k = 0; k < 20; ++k) {
+                    const double mid = t0 + span * (k + 0.5) / 20.0;
+                    if ((double)all[24 + 2 * b] <= mid && mid < (double)all[25 + 2 * b]) ++slices[k];
+                }
+            }
+            std::fprintf(stderr, "[residency] span %.1f us, workgroup-time / (%d CUs x span) = %.3f | resident workgroups per 5 %% slice:", span / 100.0,
+                         d.workgroups, busy / (span * d.workgroups));
+            for (int k = 0; k < 20; ++k) std::fprintf(stderr, " %d", slices[k]);
+            std::fprintf(stderr, "\n");
+        }
     }
 #endif
     return MPC_OK;
@@ -1197,7 +1218,7 @@ struct EntropyBuffers {
 };
 
 // carve (and grow) slot `sl`'s buffers for frames of `tiles` tiles; the symbols of the streams live in the caller's buffers
-mpc_status entropy_buffers(mpc_context* c, int sl, size_t tiles, int K, EntropyBuffers* b) {
+mpc_status entropy_buffers(mpc_context::EntropySlot& e, size_t tiles, int K, EntropyBuffers* b) {
     auto up = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
     const int S = 6 * K + 1;
     const size_t n_tc = 3 * tiles;
@@ -1212,7 +1233,6 @@ mpc_status entropy_buffers(mpc_context* c, int sl, size_t tiles, int K, EntropyB
     const size_t hist_b = tcode_b;                        // ghist, gfirst: [S][65536] words each
     const size_t dev_need = streams_b + totals_b + 6 * blk_u32 + blk_u64 + packed_b + tcode_b + tlen_b + out_b + 2 * hist_b;
     const size_t host_need = streams_b + totals_b + 2 * triples_b + out_b;
-    mpc_context::EntropySlot& e = c->ent[sl];
     if (dev_need > e.dev_bytes) {
         HIP_TRY(hipDeviceSynchronize());
         if (e.dev) (void)hipFree(e.dev);
@@ -1476,7 +1496,7 @@ static mpc_status encode_sequence(mpc_context* c, const uint8_t* const* frames, 
     EntropyBuffers ent[S];
     if (device_entropy)
         for (size_t sl = 0; sl < alloc_slots; ++sl) {
-            const mpc_status es = entropy_buffers(c, static_cast<int>(sl), tiles, K, &ent[sl]);
+            const mpc_status es = entropy_buffers(c->ent[sl], tiles, K, &ent[sl]);
             if (es != MPC_OK) return es;
         }
     struct Pending {
@@ -1683,6 +1703,9 @@ struct ContainerJob {
     size_t dev_bytes = 0;
     const uint16_t* d_counts = nullptr;
     mpc::StreamArgs sa{};
+    // a job's entropy-stage buffers are its own: the slots of the context belong to the frame pipeline (mpc_encode_image(s)) and
+    // to mpc_code_symbol_streams_device, which may run -- and re-carve or clear their tables -- between `begin` and `collect`
+    mpc_context::EntropySlot ent;
     EntropyBuffers eb;
     bool device_entropy = false;
     hipEvent_t phase1 = nullptr, done = nullptr;
@@ -1690,6 +1713,8 @@ struct ContainerJob {
     uint8_t* blob = nullptr;            // the host route's result, ready at `tables`
     size_t nblob = 0;
     ~ContainerJob() {
+        if (ent.dev) (void)hipFree(ent.dev);
+        if (ent.host) (void)hipHostFree(ent.host);
         if (dev) (void)hipFree(dev);
         if (phase1) (void)hipEventDestroy(phase1);
         if (done) (void)hipEventDestroy(done);
@@ -1787,7 +1812,7 @@ mpc_status mpc_container_job_begin(mpc_context* c, int slot, const uint16_t* d_c
     j->quant.assign(q, q + 3 * static_cast<size_t>(K));
     j->device_entropy = !host_entropy_forced();
     if (j->device_entropy) {
-        const mpc_status es = entropy_buffers(c, slot, tiles, K, &j->eb);
+        const mpc_status es = entropy_buffers(j->ent, tiles, K, &j->eb);
         if (es != MPC_OK) return es;
     }
     const int err = mpc::launch_stream_assembly(sa, j->stream);
@@ -1851,6 +1876,22 @@ mpc_status mpc_container_job_collect(mpc_context* c, int slot, uint8_t** bytes, 
     });
 }
 
+mpc_status mpc_interleave_stripe_device(mpc_context* c, const uint16_t* d_part_counts, const mpc_basis_choice* d_part_choices, int width,
+                                        int height, int tile_row_begin, int tile_row_end, uint16_t* d_frame_counts,
+                                        mpc_basis_choice* d_frame_choices, void* stream) {
+    if (!c || !d_part_counts || !d_part_choices || !d_frame_counts || !d_frame_choices) return fail(MPC_ERR_ARGUMENT, "null argument");
+    if (c->device < 0) return fail(MPC_ERR_NO_DEVICE, "context was created without a device");
+    if (width < 1 || height < 1) return fail(MPC_ERR_ARGUMENT, "bad geometry");
+    const int tiles_x = (width + 7) / 8, tiles_y = (height + 7) / 8;
+    if (tile_row_begin < 0 || tile_row_end > tiles_y || tile_row_begin >= tile_row_end)
+        return fail(MPC_ERR_ARGUMENT, "tile rows [%d,%d) outside 0..%d", tile_row_begin, tile_row_end, tiles_y);
+    HIP_TRY(hipSetDevice(c->device));
+    const int err = mpc::launch_interleave_stripe(d_part_counts, reinterpret_cast<const uint32_t*>(d_part_choices), tiles_x, tiles_y, tile_row_begin,
+                                                  tile_row_end - tile_row_begin, c->K, d_frame_counts, reinterpret_cast<uint32_t*>(d_frame_choices), stream);
+    if (err != 0) return fail(MPC_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(err)));
+    return MPC_OK;
+}
+
 mpc_status mpc_records_to_container_device(mpc_context* c, const uint16_t* d_counts, const mpc_basis_choice* d_choices, int width,
                                            int height, const double* quant, void* stream, uint8_t** bytes, size_t* nbytes) {
     if (!bytes || !nbytes) return fail(MPC_ERR_ARGUMENT, "null argument");
@@ -1882,7 +1923,7 @@ mpc_status mpc_code_symbol_streams_device(mpc_context* c, int width, int height,
     if (route) *route = 1;
     if (!host_entropy_forced()) {
         EntropyBuffers eb;
-        const mpc_status es = entropy_buffers(c, 0, tiles, K, &eb);
+        const mpc_status es = entropy_buffers(c->ent[0], tiles, K, &eb);
         if (es != MPC_OK) return es;
         struct Temp {
             void* p = nullptr;

@@ -41,36 +41,59 @@ def interleave_stripes(parts, tiles_x, tiles_y, world):
     return out.reshape((tiles_x * tiles_y,) + tail)
 
 
-def exchange_stripes(dist, mine, tiles_x, tiles_y, via_cpu=False):
-    """mine[f] = this rank's stripe of frame f (torch tensor [tiles_x * rows_mine, ...]), f = 0 .. world-1.
-    Returns parts[r] = rank r's stripe of the frame THIS rank owns (frame index = rank), exact sizes, dtype kept.
-    via_cpu: stage through host memory (gloo has no device point-to-point)."""
+def nccl_dtypes():
+    """What torch's NCCL/RCCL process group carries (torch/csrc/distributed/c10d/NCCLUtils.hpp: no 16-bit integers)."""
+    import torch
+    return {torch.uint8, torch.int8, torch.int32, torch.int64, torch.float16, torch.float32, torch.float64, torch.bfloat16, torch.bool}
+
+
+def exchange_stripes(dist, sets, tiles_x, tiles_y, via_cpu=False, recv=None):
+    """ONE batched point-to-point exchange for all record arrays of a step.
+    sets[k][f] = this rank's stripe of frame f of array k (torch tensor [tiles_x * rows_mine, ...]), f = 0 .. world-1.
+    Returns parts[k][r] = rank r's stripe of the frame THIS rank owns (frame index = rank), exact sizes; parts[k][rank] is
+    sets[k][rank] itself (no copy).  Every tensor must have a dtype RCCL carries (`nccl_dtypes`): 16-bit counts travel as bytes.
+    via_cpu: stage through host memory (gloo has no device point-to-point).  recv[k][r]: preallocated receive buffers."""
     import torch
     world, rank = dist.get_world_size(), dist.get_rank()
-    tail = tuple(mine[0].shape[1:])
-    dev = mine[0].device
-    send = [m.cpu() if via_cpu else m for m in mine]
-    parts = []
-    for r in range(world):
-        b, e = stripe_bounds(tiles_y, world, r)
-        parts.append(torch.empty((tiles_x * (e - b),) + tail, dtype=mine[0].dtype, device="cpu" if via_cpu else dev))
-    ops = []
-    for r in range(world):
-        if r == rank:
-            parts[r].copy_(send[r])
-            continue
-        ops.append(dist.P2POp(dist.isend, send[r].contiguous(), r))
-        ops.append(dist.P2POp(dist.irecv, parts[r], r))
+    ok = nccl_dtypes()
+    parts, ops = [], []
+    for k, mine in enumerate(sets):
+        if mine[0].dtype not in ok:
+            raise TypeError(f"{mine[0].dtype} cannot travel over RCCL: view it as uint8")
+        tail = tuple(mine[0].shape[1:])
+        dev = mine[0].device
+        got = []
+        for r in range(world):
+            if r == rank:
+                got.append(mine[rank])
+                continue
+            b, e = stripe_bounds(tiles_y, world, r)
+            shape = (tiles_x * (e - b),) + tail
+            if recv is not None and not via_cpu:
+                buf = recv[k][r]
+                assert tuple(buf.shape) == shape and buf.dtype == mine[0].dtype
+            else:
+                buf = torch.empty(shape, dtype=mine[0].dtype, device="cpu" if via_cpu else dev)
+            got.append(buf)
+            ops.append(dist.P2POp(dist.isend, (mine[r].cpu() if via_cpu else mine[r]).contiguous(), r))
+            ops.append(dist.P2POp(dist.irecv, buf, r))
+        parts.append(got)
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
-    return [p.to(dev) for p in parts] if via_cpu else parts
+    if via_cpu:
+        parts = [[p if r == rank else p.to(sets[k][0].device) for r, p in enumerate(got)] for k, got in enumerate(parts)]
+    return parts
 
 
 class StripedEncoder:
-    """The N > 1 path on a GPU: stripe encode of every frame (one launch), stripe exchange, interleave, this rank's frame ->
-    container bytes (stream assembly and the per-symbol entropy work on the device, code tables on the host).  `step` does one
-    step synchronously; `run` pipelines consecutive steps."""
+    """The N > 1 path on a GPU: stripe encode of every frame (one launch), stripe exchange (one batched send / receive over
+    RCCL), the stripes copied to their places in the frame this rank owns (mpc_interleave_stripe_device), that frame -> container
+    bytes (stream assembly and the per-symbol entropy work on the device, code tables on the host).  `step` does one step
+    synchronously; `run` pipelines consecutive steps.  Everything is enqueued on `stream`, which is made torch's current stream
+    for the duration (the process group orders its transfers against the current stream)."""
+
+    SLOTS = 3
 
     def __init__(self, ctx, width, height, frames, world, rank, backend):
         import torch
@@ -85,47 +108,66 @@ class StripedEncoder:
         K = ctx.K
         self.counts = torch.zeros((frames, per_frame, 3), dtype=torch.int16, device="cuda")
         self.choices = torch.zeros((frames, per_frame, 3, K), dtype=torch.int32, device="cuda")
+        tiles = self.tiles_x * self.tiles_y
+        # whole-frame records of the frame this rank owns: a container job reads them until its `collect`
+        self.frame_counts = [torch.zeros((tiles, 3), dtype=torch.int16, device="cuda") for _ in range(self.SLOTS)]
+        self.frame_choices = [torch.zeros((tiles, 3, K), dtype=torch.int32, device="cuda") for _ in range(self.SLOTS)]
+        self.recv = None
+        if not self.via_cpu:
+            rows = [stripe_bounds(self.tiles_y, world, r) for r in range(world)]
+            self.recv = [[torch.empty((self.tiles_x * (e - b), 6), dtype=torch.uint8, device="cuda") for b, e in rows],
+                         [torch.empty((self.tiles_x * (e - b), 3, K), dtype=torch.int32, device="cuda") for b, e in rows]]
         ctx.reserve(frames * per_frame)
 
-    def _records_of_my_frame(self, d_rgb, stream):
-        """stripe encode of every frame (one launch), stripe exchange, interleave: whole-frame records of the frame this rank owns,
-        all enqueued on `stream` (RCCL) or synchronous (gloo rehearsal)"""
+    def _records_of_my_frame(self, d_rgb, stream, slot):
+        """stripe encode of every frame (one launch), stripe exchange, interleave into slot `slot`'s whole-frame records"""
         W, H = self.W, self.H
         self.ctx.encode_batch_device(d_rgb.data_ptr(), self.world, W * H * 3, W, H, W * 3, self.begin, self.end,
                                      self.counts.data_ptr(), self.choices.data_ptr(), stream=stream.cuda_stream)
-        cparts = exchange_stripes(self.dist, list(self.counts), self.tiles_x, self.tiles_y, self.via_cpu)
-        hparts = exchange_stripes(self.dist, list(self.choices), self.tiles_x, self.tiles_y, self.via_cpu)
-        counts = interleave_stripes(cparts, self.tiles_x, self.tiles_y, self.world).contiguous()
-        choices = interleave_stripes(hparts, self.tiles_x, self.tiles_y, self.world).contiguous()
-        return counts, choices
+        cparts, hparts = exchange_stripes(self.dist, [list(self.counts.view(torch_uint8())), list(self.choices)], self.tiles_x,
+                                          self.tiles_y, self.via_cpu, self.recv)
+        fc, fh = self.frame_counts[slot], self.frame_choices[slot]
+        for r in range(self.world):
+            b, e = stripe_bounds(self.tiles_y, self.world, r)
+            self.ctx.interleave_stripe_device(cparts[r].data_ptr(), hparts[r].data_ptr(), W, H, b, e, fc.data_ptr(), fh.data_ptr(),
+                                              stream=stream.cuda_stream)
+        self._held = (cparts, hparts)                           # staged copies of the gloo rehearsal stay alive until the next step
+        return fc, fh
 
     def step(self, d_rgb, stream):
-        counts, choices = self._records_of_my_frame(d_rgb, stream)
-        return self.ctx.records_to_container_device(counts.data_ptr(), choices.data_ptr(), self.W, self.H, stream=stream.cuda_stream)
+        import torch
+        with torch.cuda.stream(stream):
+            counts, choices = self._records_of_my_frame(d_rgb, stream, 0)
+            return self.ctx.records_to_container_device(counts.data_ptr(), choices.data_ptr(), self.W, self.H, stream=stream.cuda_stream)
 
     def run(self, d_rgb, stream, steps, views=False):
         """`steps` steps, software-pipelined on ONE stream so that the device always has the next tile encode queued: step i's
         encode + exchange + stream assembly + entropy phase 1 are enqueued, then step i-1's code tables are built on the host
         (while the device works on step i) and its phase 2 + container copy enqueued behind, then step i-2's container is
         collected (long finished).  Same containers as `step`, in order."""
-        slots = 3
-        held = [None] * slots                                   # the records a job reads stay alive until its tables are done
+        import torch
+        slots = self.SLOTS
         out = []
-        for i in range(steps):
-            counts, choices = self._records_of_my_frame(d_rgb, stream)
-            held[i % slots] = (counts, choices)
-            self.ctx.container_job_begin(i % slots, counts.data_ptr(), choices.data_ptr(), self.W, self.H, stream=stream.cuda_stream)
-            if i >= 1:
-                self.ctx.container_job_tables((i - 1) % slots)
-            if i >= 2:
-                out.append(self.ctx.container_job_collect((i - 2) % slots, views))
-        if steps >= 1:
-            self.ctx.container_job_tables((steps - 1) % slots)
-        if steps >= 2:
-            out.append(self.ctx.container_job_collect((steps - 2) % slots, views))
-        if steps >= 1:
-            out.append(self.ctx.container_job_collect((steps - 1) % slots, views))
+        with torch.cuda.stream(stream):
+            for i in range(steps):
+                counts, choices = self._records_of_my_frame(d_rgb, stream, i % slots)       # slot i % 3 was collected at step i - 1
+                self.ctx.container_job_begin(i % slots, counts.data_ptr(), choices.data_ptr(), self.W, self.H, stream=stream.cuda_stream)
+                if i >= 1:
+                    self.ctx.container_job_tables((i - 1) % slots)
+                if i >= 2:
+                    out.append(self.ctx.container_job_collect((i - 2) % slots, views))
+            if steps >= 1:
+                self.ctx.container_job_tables((steps - 1) % slots)
+            if steps >= 2:
+                out.append(self.ctx.container_job_collect((steps - 2) % slots, views))
+            if steps >= 1:
+                out.append(self.ctx.container_job_collect((steps - 1) % slots, views))
         return out
+
+
+def torch_uint8():
+    import torch
+    return torch.uint8
 
 
 def histogram_of_records(counts, choices, K):

@@ -240,23 +240,32 @@ mpc_status mpc_elias_fano_encode(const uint16_t* sorted, size_t n, uint16_t max_
 mpc_status mpc_elias_fano_decode(const uint8_t* bytes, size_t nbytes, size_t n, uint16_t max_symbol, uint16_t* sorted, size_t* remaining_bits);
 
 /* compressed::encodeImage (CompressedImage.h:59): rgb host buffer, 3*width bytes per row; quant NULL = context
- * tables.  Tile encode on the device, entropy stage on the host. */
+ * tables.  Tile encode, stream assembly and the per-symbol work of the entropy stage (run lengths, histograms, code writing)
+ * on the device; the host builds one code table per stream; only the finished container crosses PCIe (a frame whose streams do
+ * not fit the device tables takes the host route for the entropy stage: same bytes). */
 mpc_status mpc_encode_image(mpc_context* ctx, const uint8_t* rgb, int width, int height, const double* quant,
                             uint8_t** bytes, size_t* nbytes);
 
 /* The same for a sequence of equally sized frames (what Compression.cpp does per input file, :117/:166), pipelined: the
- * host entropy stage of frame n runs while the device encodes frame n+1.  bytes[i] / nbytes[i] receive frame i's
+ * code tables of frame n are built on the host while the device encodes frame n+1.  bytes[i] / nbytes[i] receive frame i's
  * container (each to be released with mpc_free); byte-identical to n calls of mpc_encode_image.  On failure nothing is
  * returned. */
 mpc_status mpc_encode_images(mpc_context* ctx, const uint8_t* const* rgb_frames, int n_frames, int width, int height,
                              const double* quant, uint8_t** bytes, size_t* nbytes);
 
 /* The same two with the frames already resident in device memory (3*width bytes per row, tightly packed): what bench.py
- * times -- tile encode and stream assembly on the device, only the live symbols cross PCIe, entropy stage on the host. */
+ * times. */
 mpc_status mpc_encode_image_device(mpc_context* ctx, const uint8_t* d_rgb, int width, int height, const double* quant,
                                    uint8_t** bytes, size_t* nbytes);
 mpc_status mpc_encode_images_device(mpc_context* ctx, const uint8_t* const* d_rgb_frames, int n_frames, int width, int height,
                                     const double* quant, uint8_t** bytes, size_t* nbytes);
+
+/* Multi-GPU path, between the stripe exchange and the stream assembly: the records of tile rows [tile_row_begin, tile_row_end)
+ * of a frame, in the order mpc_encode_tiles_device writes a stripe (t = tx*rows + ty_local), copied to their places in the whole
+ * frame's records (t = tx*tiles_y + ty: the reference's visiting order, CompressedImage.cpp:535-537).  Asynchronous on `stream`. */
+mpc_status mpc_interleave_stripe_device(mpc_context* ctx, const uint16_t* d_part_counts, const mpc_basis_choice* d_part_choices,
+                                        int width, int height, int tile_row_begin, int tile_row_end, uint16_t* d_frame_counts,
+                                        mpc_basis_choice* d_frame_choices, void* stream);
 
 /* The second half of encodeImage (CompressedImage.cpp:555-575) for records that are already in device memory in whole-frame
  * order, tile t = tx*tiles_y + ty (a frame's owner in the multi-GPU path after the stripe exchange): stream assembly on the
@@ -268,7 +277,9 @@ mpc_status mpc_records_to_container_device(mpc_context* ctx, const uint16_t* d_c
  * stay untouched until `collect` has returned (the counts are the `lengths` stream the last kernels read).
  *   begin    stream assembly and the first phase of the entropy stage enqueued on `stream`; nothing is waited for
  *   tables   waits for that, builds the code tables on the host, enqueues the second phase and the container's copy on `stream`
- *   collect  waits for the copy; the container (mpc_free) */
+ *   collect  waits for the copy; the container (mpc_free)
+ * A job owns its buffers: any other entry point of the context (mpc_encode_image(s), mpc_decode_image, ...) may be called between
+ * `begin` and `collect`; calls on one context are serialised, not forbidden. */
 #define MPC_JOB_SLOTS 6
 mpc_status mpc_container_job_begin(mpc_context* ctx, int slot, const uint16_t* d_counts, const mpc_basis_choice* d_choices, int width,
                                    int height, const double* quant, void* stream);

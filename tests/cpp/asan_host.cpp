@@ -108,6 +108,25 @@ int main(int argc, char** argv) {
         const std::vector<uint16_t> t = mpc::filter_tiles(d8.base.data(), d8.num_base, 32, 1, &shadow);
         CHECK(t.size() == 32u * 2048u && shadow.size() == 510u && shadow[509] == 1);
     }
+    {   // the worker pool contains a throwing job: the call drains, the first exception reaches the caller, the pool stays usable
+        for (int rep = 0; rep < 20; ++rep) {
+            std::atomic<int> ran{0};
+            bool caught = false;
+            try {
+                mpc::parallel_jobs(200, [&](int i) {
+                    ++ran;
+                    if (i == 37 + rep) throw std::runtime_error("job failed");
+                });
+            } catch (const std::runtime_error& e) {
+                caught = std::strcmp(e.what(), "job failed") == 0;
+            }
+            CHECK(caught);
+            CHECK(ran.load() >= 1 && ran.load() <= 200);
+            std::atomic<int> sum{0};
+            mpc::parallel_jobs(200, [&](int i) { sum += i; });
+            CHECK(sum.load() == 199 * 200 / 2);
+        }
+    }
     {   // Huffman and run-length codes
         for (int rep = 0; rep < 60; ++rep) {
             std::vector<uint16_t> v(rng() % 5000);

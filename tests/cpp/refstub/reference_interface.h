@@ -1,10 +1,16 @@
 // reference_interface.h -- TEST SCAFFOLDING, not product code and not a build of the reference.
-// The GPU box has no /root/reference, and the reference's own headers cannot be compiled here anyway (they include Eigen and
+// The GPU box has no /root/reference, and CompressionLib's own headers cannot be compiled here anyway (they include Eigen and
 // <format>, neither present).  To compile dropin/compressionlib_dropin.cpp and a caller written like Compression.cpp in the
-// tests, this file DECLARES the part of the reference's public interface that those two touch -- names, signatures and member
-// names as in CompressionLib/inc/{CompressedImage,MatchingPursuit}.h, SimpleMatrix/inc/{mathvector,mathmatrix}.h and
-// ImageHelper/inc/image.h -- with the smallest bodies that make the value types usable (row-major double storage).  The one-line
-// headers under tests/cpp/refstub/<project>/inc/ forward here, so the drop-in's `#include "CompressedImage.h"` resolves.
+// tests, this file DECLARES the part of CompressionLib's public interface that those two touch -- names, signatures and member
+// names as in CompressionLib/inc/{CompressedImage,MatchingPursuit}.h -- over the value types math::Vector / math::Matrix /
+// img::image, which come from one of two places:
+//   * default: restated below with the smallest bodies that make them usable (row-major double storage), as in
+//     SimpleMatrix/inc/{mathvector,mathmatrix}.h and ImageHelper/inc/image.h;
+//   * -DMPC_TEST_REAL_REFERENCE_HEADERS -I <reference root>: the reference's REAL headers of those three, which compile here
+//     unmodified (tests/test_dropin.py: test_dropin_builds_against_the_reference_s_own_value_types; their member functions are
+//     then linked from SimpleMatrix/src/{mathmatrix,mathvector}.cpp compiled in place).  Only CompressedImage.h /
+//     MatchingPursuit.h stay declarations (Eigen).
+// The one-line headers under tests/cpp/refstub/<project>/inc/ forward here, so the drop-in's `#include "CompressedImage.h"` resolves.
 #pragma once
 #include <cstddef>
 #include <cstdint>
@@ -13,6 +19,11 @@
 #include <memory>
 #include <vector>
 
+#ifdef MPC_TEST_REAL_REFERENCE_HEADERS
+#include "SimpleMatrix/inc/mathmatrix.h"
+#include "SimpleMatrix/inc/mathvector.h"
+#include "ImageHelper/inc/image.h"
+#else
 namespace math {
 class Vector {
 public:
@@ -68,6 +79,7 @@ private:
 };
 }  // namespace img
 #define imRef(im, x, y) (im->access[y][x])
+#endif  // MPC_TEST_REAL_REFERENCE_HEADERS
 
 namespace Eigen {                                   // just enough of VectorXf / MatrixXf for the Fast signatures to exist
 typedef std::ptrdiff_t Index;

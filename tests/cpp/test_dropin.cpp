@@ -6,6 +6,9 @@
 //     n   encode + decodeImage + calculatePSNR, prints "PSNR <p> bytes <n>"; decoded RGB written to <out file>
 //     s   64 random patches through CalcMPDynamic with the context's closures; "<count> <deltaId> <intCoeff> ..." per patch
 //     x   a foreign closure (not made by the factory, same dictionary) is recognised by probing; a wrong one throws
+//     h   host only (no GPU): the context's tables and closures through the reference's value types -- dictionary shapes, a
+//         dynamic dictionary with repeats, FromCoeffsDynamic -- printed as text (two builds of this file, against the restated
+//         and against the reference's real math:: / img:: headers, must print the same)
 #include "CompressedImage.h"
 
 #include <cstdio>
@@ -48,7 +51,7 @@ int main(int argc, char** argv) {
     std::ofstream out(argv[6], std::ios::binary);
     try {
         std::unique_ptr<image<rgb>> imgIn = synthetic(W, H, seed);
-        if (mode == "c" || mode == "n" || mode == "s" || mode == "x") {
+        if (mode == "c" || mode == "n" || mode == "s" || mode == "x" || mode == "h") {
             std::unique_ptr<CompressionContext> context;
             if (quality == "max") {                                   // Compression.cpp:104-110
                 context = createCompressionContext(K, BlockSize, 0.0);
@@ -59,6 +62,28 @@ int main(int argc, char** argv) {
                 }
             } else {
                 context = createCompressionContext(K, BlockSize, std::atof(quality.c_str()));
+            }
+            if (mode == "h") {
+                out.precision(17);
+                out << context->K << ' ' << context->BlockSize << ' ' << context->BaseDict.Rows() << ' ' << context->BaseDict.Columns() << ' '
+                    << context->Y.DetailBasis.size() << '\n';
+                ChannelContext* chans[3] = {&context->Y, &context->U, &context->V};
+                for (int ch = 0; ch < 3; ++ch) {
+                    for (size_t i = 0; i < K; i += 7) out << chans[ch]->Quant[i] << ' ';
+                    std::vector<BasisChoice> picks(4);
+                    const unsigned short ids[4] = {3, static_cast<unsigned short>(2 * 40), static_cast<unsigned short>(2 * 37 + 1), 0};   // 3, +40, -38 (... 5), +0
+                    for (int i = 0; i < 4; ++i) { picks[i].deltaId = ids[i]; picks[i].intCoeff = static_cast<unsigned short>(2 * (i + 1)); }
+                    const math::Matrix dyn = chans[ch]->Dynamic(4, picks);
+                    double sum = 0.0;
+                    for (size_t r = 0; r < dyn.Rows(); ++r) sum += dyn.Data()[r * dyn.Columns() + (r % dyn.Columns())] * static_cast<double>(r % 5 + 1);
+                    out << dyn.Rows() << ' ' << dyn.Columns() << ' ' << sum << ' ';
+                    const math::Vector back = FromCoeffsDynamic(static_cast<int>(K), chans[ch]->Quant.Data(), picks, chans[ch]->Dynamic);
+                    for (size_t j = 0; j < back.Length(); j += 9) out << back[j] << ' ';
+                    out << '\n';
+                }
+                std::unique_ptr<image<rgb>> same = synthetic(W, H, seed);
+                out << calculatePSNR(imgIn.get(), same.get()) << '\n';
+                return 0;
             }
             if (mode == "s") {                                        // Compression.cpp:229-264
                 std::mt19937 rng(seed);

@@ -11,6 +11,7 @@ import pytest
 from conftest import ROOT
 
 EXE = os.path.join(ROOT, "tests", "cpp", "test_dropin")
+REFERENCE = "/root/reference"
 
 
 def _build():
@@ -46,6 +47,36 @@ def test_dropin_compiles_and_links_against_the_reference_interface():
                  "matching::CalcMPDynamic(int, double const*, std::vector<matching::BasisChoice_t",
                  "matching::FromCoeffsDynamic(int, double const*"):
         assert name in syms, name
+
+
+def test_dropin_builds_against_the_reference_s_own_value_types(tmp_path):
+    """The drop-in and the Compression.cpp-shaped caller compiled against the reference's REAL SimpleMatrix/inc/{mathmatrix,
+    mathvector}.h and ImageHelper/inc/image.h (they compile here unmodified; their member functions come from
+    SimpleMatrix/src/{mathmatrix,mathvector}.cpp compiled where they lie) -- only CompressedImage.h / MatchingPursuit.h stay
+    declarations, because they include Eigen (an empty submodule of the tree).  Host-only mode `h` of the caller: dictionary
+    shapes, a dynamic dictionary with repeats, FromCoeffsDynamic, calculatePSNR through the real math::Matrix / math::Vector /
+    img::image must print exactly what the build against the restated value types prints.  Build container only: nothing of
+    /root/reference exists on the GPU box."""
+    if not os.path.isdir(os.path.join(REFERENCE, "SimpleMatrix", "inc")):
+        pytest.skip("the reference tree is not present (GPU box)")
+    import imageexperiments_amd as ia
+    lib = os.path.dirname(ia.library_path())
+    real = str(tmp_path / "test_dropin_real")
+    srcs = [os.path.join(ROOT, "tests", "cpp", "test_dropin.cpp"), os.path.join(ROOT, "dropin", "compressionlib_dropin.cpp"),
+            os.path.join(REFERENCE, "SimpleMatrix", "src", "mathmatrix.cpp"), os.path.join(REFERENCE, "SimpleMatrix", "src", "mathvector.cpp")]
+    subprocess.run(["g++", "-std=c++20", "-O1", "-ffp-contract=off", "-DMPC_TEST_REAL_REFERENCE_HEADERS", "-I", REFERENCE,
+                    "-I", os.path.join(ROOT, "tests", "cpp", "refstub", "CompressionLib", "inc"), "-I", os.path.join(ROOT, "include")]
+                   + srcs + ["-o", real, "-L", lib, "-lmpcodec", f"-Wl,-rpath,{lib}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    outs = []
+    for exe in (real, _build()):
+        for quality in ("3.5", "max"):
+            out = tmp_path / (os.path.basename(exe) + quality + ".txt")
+            r = subprocess.run([exe, "h", "96", "64", "31", quality, str(out)], capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, (exe, r.returncode, r.stdout, r.stderr)
+            outs.append(out.read_text())
+    assert outs[0] == outs[2] and outs[1] == outs[3]
+    first = outs[0].split("\n")[0].split()
+    assert first == ["32", "8", "510", "64", "510"]
 
 
 @pytest.mark.gpu

@@ -45,16 +45,37 @@ def _worker(rank, world, port, W, H, K, q, out_dir):
         full_c = oc.reshape(tiles_x, tiles_y, 3)
         full_h = (od.astype(np.uint32) | (ok.astype(np.uint32) << 16)).reshape(tiles_x, tiles_y, 3, K)
         full_h = np.where(np.arange(K)[None, None, None, :] < full_c[..., None], full_h, 0)
-        mine_c.append(torch.from_numpy(np.ascontiguousarray(full_c[:, b:e].reshape(-1, 3)).view(np.int16)))
+        # 16-bit counts travel as bytes: RCCL has no 16-bit integer type (exchange_stripes refuses one)
+        mine_c.append(torch.from_numpy(np.ascontiguousarray(full_c[:, b:e].reshape(-1, 3)).view(np.uint8)))
         mine_h.append(torch.from_numpy(np.ascontiguousarray(full_h[:, b:e].reshape(-1, 3, K)).view(np.int32)))
-    cparts = sh.exchange_stripes(dist, mine_c, tiles_x, tiles_y)
-    hparts = sh.exchange_stripes(dist, mine_h, tiles_x, tiles_y)
+    verdict = "ok"
+    try:
+        sh.exchange_stripes(dist, [[t.view(torch.int16) for t in mine_c]], tiles_x, tiles_y)
+        verdict = "a 16-bit tensor was accepted for the exchange"
+    except TypeError:
+        pass
+    cparts, hparts = sh.exchange_stripes(dist, [mine_c, mine_h], tiles_x, tiles_y)
+    for part in cparts + hparts:
+        if part.dtype not in sh.nccl_dtypes():
+            verdict = f"{part.dtype} handed to the process group"
     counts = sh.interleave_stripes(cparts, tiles_x, tiles_y, world).numpy().view(np.uint16)
     choices = sh.interleave_stripes(hparts, tiles_x, tiles_y, world).numpy().view(np.uint32)
     blob = ia.assemble_streams(W, H, K, 8, octx.quant, counts, choices)      # frame `rank` is mine
     ref = octx.encode_image(frames[rank])
+    if blob != ref:
+        verdict = f"bytes differ: {len(blob)} vs {len(ref)}"
+    # the symbol histograms of the stripes, all-reduced, are the whole frame's (frame 0; SURVEY 8e's one collective)
+    oc, od, ok, _, _ = octx.encode_tiles(frames[0])
+    full_c = oc.reshape(tiles_x, tiles_y, 3)
+    full_h = (od.astype(np.uint32) | (ok.astype(np.uint32) << 16)).reshape(tiles_x, tiles_y, 3, K)
+    mine = sh.histogram_of_records(full_c[:, b:e].reshape(-1, 3), full_h[:, b:e].reshape(-1, 3, K), K)
+    total = sh.allreduce_histogram(dist, mine)
+    if not (total == sh.histogram_of_records(full_c.reshape(-1, 3), full_h.reshape(-1, 3, K), K)).all():
+        verdict = "all-reduced stripe histograms differ from the frame's"
+    if int(total[0].sum()) != 3 * tiles_x * tiles_y:
+        verdict = "the lengths histogram does not count every tile-channel"
     with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
-        f.write("ok" if blob == ref else f"bytes differ: {len(blob)} vs {len(ref)}")
+        f.write(verdict)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -38,7 +38,7 @@ FRAMES = [
     ("natural_mn_k32_q3.5", "mn", 4928, 3264, 32, 3.5, 0),
     ("natural_jpg_k32_q3.5", "jpg", 4928, 3264, 32, 3.5, 0),
     ("odd_1003x517_k32_q3.5", "synthetic", 1003, 517, 32, 3.5, 777),      # ragged edges in both directions
-    ("batch_frame1_k32_q3.5", "synthetic", 4928, 3264, 32, 3.5, 12346),   # configs[3]: frame f uses seed 12345 + f
+] + [(f"batch_frame{f}_k32_q3.5", "synthetic", 4928, 3264, 32, 3.5, 12345 + f) for f in range(1, 8)     # configs[3]: frame f uses seed 12345 + f
 ] + [(f"raise_k32_q{q:.1f}", "synthetic", 4928, 3264, 32, q, 12345) for q in (2.0, 2.5, 3.0, 3.5, 4.0, 4.5, 5.0, 5.5, 6.0)] + [
     # the `...Fast` (float) flavour, by oracle/mpo_fast.c: a DEFINITION of the float mode, parity unpinned against the reference
     ("fast_1080p_k8_q3.5", "synthetic", 1920, 1080, 8, 3.5, 12345),
