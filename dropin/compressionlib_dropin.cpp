@@ -48,23 +48,56 @@ int device_ordinal() {
     return v && *v ? std::atoi(v) : 0;
 }
 
+// MPC_DEVICES=0,1,2,...: encodeImage stripes every frame's tile rows over these devices (mpc_encode_images_multi; a device may be
+// named more than once: one lane each).  Unset or a single entry: one device, MPC_DEVICE (default 0).
+std::vector<int> device_list() {
+    std::vector<int> out;
+    if (const char* v = std::getenv("MPC_DEVICES")) {
+        const char* p = v;
+        while (*p) {
+            char* end = nullptr;
+            const long d = std::strtol(p, &end, 10);
+            if (end == p) break;
+            out.push_back(static_cast<int>(d));
+            p = *end == ',' ? end + 1 : end;
+        }
+    }
+    if (out.empty()) out.push_back(device_ordinal());
+    return out;
+}
+
 // one mpc_context per (K, block size): the dictionary does not depend on the bit allocation, the quantisers travel as
 // arguments of every call (Compression.cpp:104-110 overwrites them in place for "max")
 struct Handles {
     std::mutex lock;
     std::map<std::pair<size_t, size_t>, mpc_context*> by_shape;
     // fast: the float flavour (its own context: the flag is per context; the device dictionary is shared anyway)
+    std::map<std::pair<size_t, size_t>, std::vector<mpc_context*>> lanes_by_shape;    // MPC_DEVICES: one context per lane
     mpc_context* get(size_t K, size_t blockSize, bool fast = false) {
         std::lock_guard<std::mutex> hold(lock);
         mpc_context*& h = by_shape[{2 * K + (fast ? 1 : 0), blockSize}];
         if (!h) {
-            check(mpc_context_create(static_cast<int>(K), static_cast<int>(blockSize), 3.5, device_ordinal(), &h));
+            check(mpc_context_create(static_cast<int>(K), static_cast<int>(blockSize), 3.5, device_list()[0], &h));
             if (fast) check(mpc_context_set_fast(h, 1));
         }
         return h;
     }
+    const std::vector<mpc_context*>& lanes(size_t K, size_t blockSize, bool fast = false) {
+        std::lock_guard<std::mutex> hold(lock);
+        std::vector<mpc_context*>& v = lanes_by_shape[{2 * K + (fast ? 1 : 0), blockSize}];
+        if (v.empty())
+            for (int device : device_list()) {
+                mpc_context* h = nullptr;
+                check(mpc_context_create(static_cast<int>(K), static_cast<int>(blockSize), 3.5, device, &h));
+                v.push_back(h);
+                if (fast) check(mpc_context_set_fast(h, 1));
+            }
+        return v;
+    }
     ~Handles() {
         for (auto& kv : by_shape) mpc_context_destroy(kv.second);
+        for (auto& kv : lanes_by_shape)
+            for (mpc_context* h : kv.second) mpc_context_destroy(h);
     }
 };
 Handles& handles() {
@@ -208,8 +241,15 @@ std::unique_ptr<uint8_t[]> encode(const img::image<img::rgb>* imgIn, size_t K, s
     std::memcpy(q.data() + 2 * K, qV, K * sizeof(double));
     uint8_t* bytes = nullptr;
     size_t n = 0;
-    check(mpc_encode_image(handles().get(K, blockSize, fast), reinterpret_cast<const uint8_t*>(imgIn->data), static_cast<int>(imgIn->width()),
-                           static_cast<int>(imgIn->height()), q.data(), &bytes, &n));
+    if (device_list().size() > 1 && (imgIn->height() + 7) / 8 >= device_list().size()) {          // the frame's tile rows over several GPUs
+        const std::vector<mpc_context*>& lanes = handles().lanes(K, blockSize, fast);
+        const uint8_t* frame = reinterpret_cast<const uint8_t*>(imgIn->data);
+        check(mpc_encode_images_multi(lanes.data(), static_cast<int>(lanes.size()), &frame, 1, static_cast<int>(imgIn->width()),
+                                      static_cast<int>(imgIn->height()), q.data(), &bytes, &n));
+    } else {
+        check(mpc_encode_image(handles().get(K, blockSize, fast), reinterpret_cast<const uint8_t*>(imgIn->data), static_cast<int>(imgIn->width()),
+                               static_cast<int>(imgIn->height()), q.data(), &bytes, &n));
+    }
     std::unique_ptr<uint8_t[]> out = std::make_unique<uint8_t[]>(n ? n : 1);
     std::memcpy(out.get(), bytes, n);
     mpc_free(bytes);

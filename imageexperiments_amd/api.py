@@ -110,6 +110,11 @@ def _bind_bitstream(L):
     L.mpc_rle_decode.argtypes = [_u16p, C.c_size_t, C.POINTER(_u16p), C.POINTER(C.c_size_t)]
     L.mpc_encode_image.argtypes = [vp, _u8p, C.c_int, C.c_int, _dp, C.POINTER(_u8p), C.POINTER(C.c_size_t)]
     L.mpc_encode_images.argtypes = [vp, C.POINTER(_u8p), C.c_int, C.c_int, C.c_int, _dp, C.POINTER(_u8p), C.POINTER(C.c_size_t)]
+    try:
+        L.mpc_encode_images_multi.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(_u8p), C.c_int, C.c_int, C.c_int, _dp, C.POINTER(_u8p), C.POINTER(C.c_size_t)]
+    except AttributeError:
+        if not os.environ.get("MPCODEC_LIB"):
+            raise
     L.mpc_encode_images_device.argtypes = [vp, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, _dp, C.POINTER(_u8p), C.POINTER(C.c_size_t)]
     L.mpc_records_to_container_device.argtypes = [vp, vp, vp, C.c_int, C.c_int, _dp, vp, C.POINTER(_u8p), C.POINTER(C.c_size_t)]
     try:
@@ -616,6 +621,29 @@ class CompressionContext:
                                         choices.ctypes.data_as(C.c_void_p), counts.ctypes.data_as(_u16p),
                                         energy.ctypes.data_as(_dp), swept.ctypes.data_as(_u32p)))
         return counts, choices, energy, swept
+
+
+def encode_images_multi(contexts, frames, quant=None, views=False):
+    """mpc_encode_images_multi: frames (host, equal sizes) through several contexts, one per device lane: every frame's tile rows
+    striped over the lanes, the stripes pulled to the frame's owner, one container per frame (byte-identical to encode_image)."""
+    L = load_library()
+    frames = [np.ascontiguousarray(f, np.uint8) for f in frames]
+    H, W = frames[0].shape[:2]
+    if any(f.shape[:2] != (H, W) for f in frames):
+        raise ValueError("frames must have the same size")
+    K = contexts[0].K
+    qp = None
+    if quant is not None:
+        quant = np.ascontiguousarray(quant, np.float64).reshape(3, K)
+        qp = quant.ctypes.data_as(_dp)
+    n = len(frames)
+    handles = (C.c_void_p * len(contexts))(*[c.h for c in contexts])
+    ptrs = (_u8p * n)(*[f.ctypes.data_as(_u8p) for f in frames])
+    outs = (_u8p * n)()
+    sizes = (C.c_size_t * n)()
+    _check(L.mpc_encode_images_multi(handles, len(contexts), ptrs, n, W, H, qp, outs, sizes))
+    take = _take_view if views else _take_bytes
+    return [take(L, outs[i], C.c_size_t(sizes[i])) for i in range(n)]
 
 
 def create_compression_context(K=32, block_size=8, bpp=3.5, device=-1):

@@ -9,8 +9,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libmpcodec.so")
-SOURCES = ["host_dictionary.cpp", "host_bitstream.cpp", "host_codec.cpp", "host_stats.cpp", "mp_kernels.hip", "mp_pursuit.hip", "mp_streams.hip", "mp_entropy.hip", "mpcodec_capi.cpp"]
-HEADERS = ["host_dictionary.h", "host_bitstream.h", "host_codec.h", "host_stats.h", "mp_device.h", os.path.join("..", "..", "include", "mpcodec.h")]
+SOURCES = ["host_dictionary.cpp", "host_bitstream.cpp", "host_codec.cpp", "host_stats.cpp", "mp_kernels.hip", "mp_pursuit.hip", "mp_streams.hip", "mp_entropy.hip", "mpcodec_capi.cpp", "mpcodec_multi.cpp"]
+HEADERS = ["host_dictionary.h", "host_bitstream.h", "host_codec.h", "host_stats.h", "mp_device.h", "mpc_internal.h", os.path.join("..", "..", "include", "mpcodec.h")]
 # -ffp-contract=off: host and device must round every mul and add separately (the reference is built
 # with MSVC /fp:precise and the integer outputs depend on it).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-pthread",

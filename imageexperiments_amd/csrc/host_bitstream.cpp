@@ -640,18 +640,95 @@ bool huffman_decode(BitReader& in, std::vector<uint16_t>& out) {
         pair_symbols[w] = static_cast<uint32_t>(table[h1 >> 5]) | (static_cast<uint32_t>(table[h2 >> 5]) << 16);
         pair_bits[w] = static_cast<uint8_t>(l1 + (h2 & 31u));
     }
+    // One table for the fast loop: symbols (2 x 16 bits), bits consumed (8), symbols decoded (0 = not here: a code longer than
+    // the table's window, or the pseudo-EOF -- the careful loop below takes those, and everything within eight bytes of the end).
+    std::vector<uint64_t> fast(lut.size(), 0);
+    for (uint32_t w = 0; w < lut.size(); ++w) {
+        if (pair_bits[w]) fast[w] = static_cast<uint64_t>(pair_symbols[w]) | (static_cast<uint64_t>(pair_bits[w]) << 32) | (2ULL << 40);
+        else if (lut[w] != 0 && (lut[w] >> 5) != eof_entry)
+            fast[w] = static_cast<uint64_t>(table[lut[w] >> 5]) | (static_cast<uint64_t>(lut[w] & 31u) << 32) | (1ULL << 40);
+    }
+    // Codes longer than the table's window, in the fast loop: when no length is over-subscribed (first_code[l] + counts[l-1] <=
+    // 2^l for every l -- true of every table an encoder writes), the codes of the used lengths, left-aligned, tile [0, end) in
+    // order of length, so "the first length at which the accumulated value is a code" is the one whose interval holds the next
+    // bits: one comparison per used length.  Any other table takes the reference's test length by length.
+    bool tiled = true;
+    std::vector<uint64_t> end_left(static_cast<size_t>(max_length) + 1, 0);      // left-aligned (64-bit) end of length l's codes
+    for (int l = 1; l <= max_length; ++l) {
+        if (!counts[l - 1]) continue;
+        const uint64_t end = static_cast<uint64_t>(first_code[l]) + counts[l - 1];
+        if (end > (1ULL << l)) { tiled = false; break; }
+        end_left[l] = end << (64 - l);                                           // end == 2^l wraps to 0: treated below
+    }
+    const uint8_t* const bytes = in.data();
+    const size_t total_bits = in.size_bits();
+    const size_t safe = total_bits >= 64 ? total_bits - 64 : 0;         // an 8-byte load at bit `pos` stays inside while pos <= safe
+    // the symbols go to out[o++]; `out` is kept larger than o (grown geometrically, cut to o on the way out)
+    size_t o = out.size();
+    struct Trim {
+        std::vector<uint16_t>& v;
+        size_t& n;
+        ~Trim() { v.resize(n); }
+    } trim{out, o};
+    auto room = [&](size_t more) {
+        if (out.size() < o + more) out.resize(std::max<size_t>(out.size() + out.size() / 2, o + more + 4096));
+    };
     for (;;) {
+        if (total_bits >= 64) {
+            size_t pos = in.position();
+            while (pos <= safe) {
+                room(16);
+                uint64_t w;
+                std::memcpy(&w, bytes + (pos >> 3), 8);
+                w = __builtin_bswap64(w) << (pos & 7);                      // at least 57 valid bits
+                unsigned used = 0;
+                uint16_t* dst = out.data() + o;
+                uint16_t* const stop = dst + 14;
+                bool careful = false;
+                while (dst < stop && used + kLutBits <= 57) {
+                    const uint32_t idx = static_cast<uint32_t>((w << used) >> (64 - kLutBits));
+                    const uint64_t e = fast[idx];
+                    if ((e >> 40) != 0) {
+                        dst[0] = static_cast<uint16_t>(e);
+                        dst[1] = static_cast<uint16_t>(e >> 16);
+                        dst += (e >> 40);
+                        used += static_cast<unsigned>((e >> 32) & 0xFFu);
+                        continue;
+                    }
+                    if (lut[idx] != 0) { careful = true; break; }            // the pseudo-EOF
+                    if (used + static_cast<unsigned>(max_length) > 57) break; // a longer code: from a fresh word
+                    int l = kLutBits + 1;
+                    uint32_t acc = 0;
+                    const uint64_t x = w << used;
+                    if (tiled) {
+                        for (; l <= max_length; ++l)
+                            if (counts[l - 1] && (x < end_left[l] || end_left[l] == 0)) break;
+                        if (l <= max_length) {
+                            acc = static_cast<uint32_t>(x >> (64 - l));
+                            if (acc < first_code[l]) l = max_length + 1;         // below every longer code: not a code at all
+                        }
+                    } else {
+                        for (; l <= max_length; ++l) {                           // the reference's test per length, on the word
+                            acc = static_cast<uint32_t>(x >> (64 - l));
+                            if (counts[l - 1] && acc >= first_code[l] && acc - first_code[l] < counts[l - 1]) break;
+                        }
+                    }
+                    if (l > max_length) { careful = true; break; }           // no code: the careful loop fails as the reference does
+                    const uint32_t entry = first_index[l] + (acc - first_code[l]);
+                    if (entry == eof_entry) { careful = true; break; }
+                    *dst++ = table[entry];
+                    used += static_cast<unsigned>(l);
+                }
+                o = static_cast<size_t>(dst - out.data());
+                pos += used;
+                if (careful) break;
+            }
+            in.set_position(pos);
+        }
+        // one symbol the careful way (a long code, the pseudo-EOF, the last bytes of the data)
         const size_t left = in.remaining();
         if (left == 0) return false;
         const uint32_t window = in.peek32();
-        const uint32_t both = pair_bits[window >> (32 - kLutBits)];
-        if (both != 0 && both <= left) {
-            const uint32_t syms = pair_symbols[window >> (32 - kLutBits)];
-            out.push_back(static_cast<uint16_t>(syms & 0xFFFFu));
-            out.push_back(static_cast<uint16_t>(syms >> 16));
-            in.skip(both);
-            continue;
-        }
         uint32_t entry = 0;
         int used = 0;
         const uint32_t hit = lut[window >> (32 - kLutBits)];
@@ -671,7 +748,8 @@ bool huffman_decode(BitReader& in, std::vector<uint16_t>& out) {
         }
         in.skip(static_cast<size_t>(used));
         if (entry == static_cast<uint32_t>(total) - 1u) return true;
-        out.push_back(table[entry]);
+        room(1);
+        out[o++] = table[entry];
     }
 }
 
@@ -858,8 +936,38 @@ bool read_huffman_or_golomb(BitReader& in, size_t length, std::vector<uint16_t>&
     const uint32_t m = static_cast<uint32_t>(in.get(16));
     if (m == 0) return false;
     if (length > in.remaining()) return false;                  // every Golomb code takes at least one bit: a lying header
-    out.reserve(out.size() + length);
-    for (size_t i = 0; i < length; ++i) out.push_back(static_cast<uint16_t>(golomb_read(m, in)));
+    const size_t first = out.size();
+    out.resize(first + length);
+    uint16_t* dst = out.data() + first;
+    size_t i = 0;
+    {   // whole 64-bit words while eight bytes remain: unary part by counting leading ones, remainder from the same word
+        const uint32_t b = bit_width(m), limit = (1u << (b + 1)) - m;
+        const uint8_t* const bytes = in.data();
+        const size_t total_bits = in.size_bits();
+        if (total_bits >= 64) {
+            const size_t safe = total_bits - 64;
+            size_t pos = in.position();
+            while (i < length && pos <= safe) {
+                uint64_t w;
+                std::memcpy(&w, bytes + (pos >> 3), 8);
+                w = __builtin_bswap64(w) << (pos & 7);                      // at least 57 valid bits
+                const unsigned ones = static_cast<unsigned>(__builtin_clzll(~w | 1ULL));
+                if (ones + 1 + b + 1 > 57) break;                           // a long unary run: the careful reader
+                const uint64_t rest = w << (ones + 1);
+                const uint32_t head = b ? static_cast<uint32_t>(rest >> (64 - b)) : 0u;
+                uint32_t rem = head;
+                unsigned used = ones + 1 + b;
+                if (head >= limit) {
+                    rem = (head << 1) + static_cast<uint32_t>((rest >> (63 - b)) & 1ULL) - limit;
+                    ++used;
+                }
+                dst[i++] = static_cast<uint16_t>(ones * m + rem);
+                pos += used;
+            }
+            in.set_position(pos);
+        }
+    }
+    for (; i < length; ++i) dst[i] = static_cast<uint16_t>(golomb_read(m, in));
     return true;
 }
 
@@ -895,6 +1003,10 @@ int host_threads() {
 class WorkerPool {
 public:
     static WorkerPool& instance() {
+        static WorkerPool pool;
+        return pool;
+    }
+    static WorkerPool& io_instance() {                      // a second pool: frame uploads run beside the entropy stage's jobs
         static WorkerPool pool;
         return pool;
     }
@@ -1008,6 +1120,15 @@ BitWriter container_head(int width, int height, int K, int block_size, const dou
 }
 
 void parallel_jobs(int n, const std::function<void(int)>& body) { parallel_for(n, body); }
+
+void parallel_io_jobs(int n, int workers, const std::function<void(int)>& body) {
+    workers = std::min(std::min(workers, host_threads()), n);
+    if (workers <= 1) {
+        for (int i = 0; i < n; ++i) body(i);
+        return;
+    }
+    WorkerPool::io_instance().run(n, workers, body);
+}
 
 std::vector<uint8_t> write_compressed(const Streams& s) {
     const int K = s.K;

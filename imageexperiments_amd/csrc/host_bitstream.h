@@ -37,6 +37,11 @@ public:
     // the next 32 bits left-aligned (zero beyond the end), without consuming them; skip() consumes
     uint32_t peek32() const;
     void skip(size_t bits) { pos_ += bits; }
+    // for the decoders' fast loops (they read whole 64-bit words while at least eight bytes remain and fall back to get / peek32)
+    const uint8_t* data() const { return p_; }
+    size_t position() const { return pos_; }
+    size_t size_bits() const { return nbits_; }
+    void set_position(size_t bit) { pos_ = bit; }
 private:
     const uint8_t* p_;
     size_t nbits_;
@@ -116,6 +121,8 @@ BitWriter container_head(int width, int height, int K, int block_size, const dou
 void or_bits(uint8_t* dst, size_t dst_bytes, size_t bit_offset, const BitWriter& piece);
 // body(0..n-1) on the entropy stage's worker pool
 void parallel_jobs(int n, const std::function<void(int)>& body);
+// the same on a second pool of at most `workers` threads (the calling thread included): copies that run beside the entropy stage
+void parallel_io_jobs(int n, int workers, const std::function<void(int)>& body);
 
 // encode_symbol_streams_malloc through plan_stream / or_bits, the device's share (statistics, code writing) done on the host
 uint8_t* encode_symbol_streams_by_plan_malloc(int width, int height, int K, int block_size, const double* quant, const uint16_t* counts,

@@ -6,9 +6,9 @@
 //                    blocks, exact evaluation of the survivors in the reference's arithmetic (PursuitArgs, launch_pursuit)
 //   mp_streams.hip   stream assembly: the records -> the container's 6K symbol streams, live symbols only (StreamArgs)
 //   mp_entropy.hip   the per-symbol work of the entropy stage: run lengths, histograms, first appearances, code writing (EntropyArgs)
-//   mp_kernels.hip   the decoder, the symbol histogram, and the STEP-SYNCHRONOUS pursuit of round 1 (a short sequence of kernels
-//                    per MP step over the active tile-channels: init, fill, filter, detail, finish, update), kept behind
-//                    MPC_PATH=steps / MPC_FILTER=0 as the product's own cross-check (its exhaustive double sweeps need no screen)
+//   mp_kernels.hip   the decoder, the symbol histogram, and the product's own cross-check of the tile encoder: a STEP-SYNCHRONOUS
+//                    pursuit that correlates every row exactly (a short sequence of kernels per MP step over the active
+//                    tile-channels: init, fill, base sweep, detail sweep, finish, update), behind MPC_PATH=steps / MPC_FILTER=0
 // The step-synchronous kernels' layout follows (Workspace, enqueue_pursuit); the persistent kernel's is further down.
 #pragma once
 #include <cstddef>
@@ -36,9 +36,6 @@ struct DictDevice {
     const int32_t* block_rows;       // [num_base]
     int block0_rows;                 // block_rows[0] (host copy)
     const int32_t* block_row_off;    // [num_base+1]
-    // split-bfloat16 copies for the filter pass, in MFMA operand order (host_dictionary.h: filter_tiles), 2048 halves per tile
-    const uint16_t* base_f32;        // [kBaseFilterTiles][2048]: base rows 0..511 (510 + 2 zero rows)
-    const uint16_t* detail_f32;      // [3][num_base][kBlockFilterTiles][2048]: every detail block padded to 64 rows
 };
 
 // Per-batch device workspace (all device pointers). cap = max tile-channels per batch.
@@ -153,6 +150,7 @@ struct PursuitArgs {
     int width, height;
     long long row_stride, frame_stride;
     int tile_row_begin, tile_rows, tiles_x;
+    int rgb_aligned8;                // rgb, row_stride and frame_stride are multiples of 8: whole tiles are read as 8-byte words
     const double* vec_in;
     int vec_channel;
     long long n_tc[3];               // tile-channels of each channel (tiles of the stripe x frames; vector mode: only vec_channel's is not 0)

@@ -1,17 +1,15 @@
-// mp_kernels.hip -- product: hand-written gfx950 (CDNA4, wave64) kernels of the quantized
-// matching-pursuit tile encoder.  See mp_device.h for the pipeline.  Integer outputs must equal the reference's
-// double path (MatchingPursuit.cpp:39-74) bit for bit, so every value that decides anything is IEEE double with
-// separately rounded mul/add (-ffp-contract=off) in the reference's order:
+// mp_kernels.hip -- product: the decoder, the symbol histogram, the planar re-ordering of records, and the product's own
+// CROSS-CHECK of the tile encoder: a step-synchronous pursuit that correlates EVERY dictionary row in the reference's arithmetic
+// (MPC_PATH=steps / MPC_FILTER=0; tests/test_gpu_parity.py compares it with the persistent kernel of mp_pursuit.hip, which
+// screens the rows first).  Integer outputs must equal the reference's double path (MatchingPursuit.cpp:39-74) bit for bit, so
+// every value that decides anything is IEEE double with separately rounded mul/add (-ffp-contract=off) in the reference's order:
 //     tot = 0; tot += row[j] * r[j]   (j ascending, mathmatrix.cpp:436-444)
-// Two ways to find the row Select() returns:
-//   * filtered sweeps (default): split-bfloat16 MFMA approximations of ALL rows with a proven error bound pick the
-//     one or two rows per tile-channel that can be the maximum; only those get the dot product above
-//     (mp_filter_wave_kernel, mp_detail_filter_kernel; comment block "filtered sweeps").
-//   * exhaustive sweeps (MPC_FILTER=0, the product's own cross-check): every row gets it -- r (one tile-channel per
-//     lane) lives in 128 VGPRs, the row is wave-uniform and arrives through the scalar data cache (s_load_dwordx16
-//     -> SGPR operand of v_mul_f64).  SMEM returns out of order, so the only usable wait is lgkmcnt(0): the loop
-//     keeps exactly ONE 16-double group load in flight (mp_base_kernel, mp_detail_kernel; measured:
-//     tools/ubench_scalar_sweep.hip).
+// Exhaustive sweeps: r (one tile-channel per lane) lives in 128 VGPRs, the row is wave-uniform and arrives through the scalar
+// data cache (s_load_dwordx16 -> SGPR operand of v_mul_f64).  SMEM returns out of order, so the only usable wait is
+// lgkmcnt(0): the loop keeps exactly ONE 16-double group load in flight (mp_base_kernel, mp_detail_kernel; measured:
+// tools/ubench_scalar_sweep.hip).  Per MP step: init / fill (bucket the active tile-channels by unlocked block), base sweep,
+// detail sweep, finish (argmax in dictionary order, quantise, record, unlock), update.  (The step-synchronous MFMA filter
+// kernels of round 1 are gone: the persistent kernel replaced them.)
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include <stdint.h>
@@ -274,629 +272,6 @@ __global__ __launch_bounds__(64, 3) void mp_base_kernel(const Workspace ws, cons
     }
 }
 
-// --------------------------------------------------------------------------------------------------
-// filtered sweeps.  The argmax of Select() only needs the exact projection of the rows that can be the
-// maximum.  So: (1) approximate ALL projections of a group of 16 tile-channels in split bfloat16 on the matrix
-// cores, (2) keep, per tile-channel, the rows whose approximation is within 2E of the largest one, (3) evaluate
-// only those in the reference's arithmetic (sequential double dot product, mathmatrix.cpp:436-444) and pick the
-// first strict maximum among them in row order.  The result is bit-identical to sweeping every row:
-//   * the approximation is a split-bfloat16 product on v_mfma_f32_16x16x32_bf16: residual and row elements are
-//     x = hi + lo + e, hi = bf16(x), lo = bf16(x - hi), |e| <= 2^-16 |x| (u = 2^-8 per rounding), and the three MFMAs
-//     hi*hi + hi*lo + lo*hi leave out lo*lo <= 2^-16 |r_j b_j|: at most 3 * 2^-16 * sum|r_j b_j| in all.  The products
-//     of two 8-bit significands are exact in f32; accumulating 6 x 32 of them in f32 (any order, any rounding mode)
-//     adds at most 6 * 33 * 2^-23 of sum|r_j b_j|.  With sum|r_j b_j| <= |r|_2 |b|_2 and |b|_2 <= 1 + 2^-50 that is
-//     < 7.0e-5 |r|_2, plus < 2^-110 where operands or products are subnormal; the reference's double value differs
-//     from the real dot product by < 2^-46 |r|_2.  E = 2^-13 |r~|_2 + 2^-100 (r~ = the f32-rounded residual) leaves a
-//     factor ~1.7 over all of it.
-//   * let j* be the row Select() returns (lowest index with maximal exact |p|) and j~ the approximate maximum:
-//     approx|p_j*| >= |p_j*| - E >= |p_j~| - E >= approx|p_j~| - 2E, so j* is kept -- as is every row tying with it.
-//   * overflow / NaN anywhere makes the comparison `approx < threshold` false: the row is kept and evaluated.
-//   * the threshold may use the largest approximation over ANY subset of the rows the tile-channel can choose from:
-//     a smaller maximum only lowers it.  Base rows and block 0 share one (mp_filter_wave_kernel), which it also leaves in
-//     approx_max[] for the detail blocks (mp_detail_filter_kernel): a block whose best row is far below the base
-//     maximum yields no survivor at all and reports "none" (index -1), which the finish kernel skips.
-//   * rows that are +-copies of an earlier row (base row 509 = -row 0) are zero in the filter copy: they tie with the
-//     earlier row exactly and can never be returned (host_dictionary.cpp: filter_tiles).
-// --------------------------------------------------------------------------------------------------
-namespace {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int kFilterGroup = 16;                                          // tile-channels per MFMA column block
-constexpr int kStageStride = N + 1;                                       // doubles per staged residual (+1: bank spread)
-constexpr float kFilterSlack = 0x1p-13f;
-constexpr float kFilterAbs = 0x1p-100f;
-
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
-
-__device__ __forceinline__ unsigned bf16_bits(float x)       // round to nearest even, like host_dictionary.cpp: bf16_round
-{
-    const unsigned bits = __float_as_uint(x);
-    return (bits + 0x7FFFu + ((bits >> 16) & 1u)) >> 16;
-}
-
-// B operand of the 16x16x32 MFMAs for 16 staged residuals: lane (slot = l & 15, h = l >> 4) holds, for kk = 0, 1, the
-// eight elements r~[slot][32kk + 8h + j] split into hi[kk] and lo[kk]; also returns |r~[slot]|^2 (summed over the
-// four h lanes)
-__device__ __forceinline__ double load_b_operand(bf16x8 (&hi)[2], bf16x8 (&lo)[2], const double* stage, int lane)
-{
-    const double* src = stage + (lane & 15) * kStageStride + 8 * (lane >> 4);
-    double ss = 0.0;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float x = (float)src[32 * kk + j];
-            ss += (double)x * (double)x;
-            const unsigned h = bf16_bits(x);
-            const unsigned l = bf16_bits(x - __uint_as_float(h << 16));
-            hi[kk][j] = (short)h;
-            lo[kk][j] = (short)l;
-        }
-    ss += __shfl_xor(ss, 16);
-    ss += __shfl_xor(ss, 32);
-    return ss;
-}
-
-// one 16-row tile of the filter copy (four 16-byte operands per lane: hi/lo x two k halves) against the B operand
-__device__ __forceinline__ f32x4 filter_tile_mfma(const uint4 (&a)[4], const bf16x8 (&hi)[2], const bf16x8 (&lo)[2])
-{
-    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-        bf16x8 ah, al;
-        __builtin_memcpy(&ah, &a[2 * kk + 0], 16);
-        __builtin_memcpy(&al, &a[2 * kk + 1], 16);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, hi[kk], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, lo[kk], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, hi[kk], acc, 0, 0, 0);
-    }
-    return acc;
-}
-
-// mask of the lowest n bits (n may be <= 0 or >= 32)
-__device__ __forceinline__ unsigned low_bits(int n) { return n <= 0 ? 0u : (n >= 32 ? 0xFFFFFFFFu : (1u << n) - 1u); }
-
-// keep the better of two (value, row) results of disjoint row sets: larger |value|, on a tie the lower row
-__device__ __forceinline__ void keep_better(double& v, int& i, double ov, int oi)
-{
-    if (oi >= 0 && (i < 0 || __builtin_fabs(ov) > __builtin_fabs(v) || (__builtin_fabs(ov) == __builtin_fabs(v) && oi < i))) {
-        v = ov;
-        i = oi;
-    }
-}
-
-// Exact evaluation of the surviving rows, cooperatively by one wave.  Lane (slot, sub) holds its survivors as bit
-// masks (bit i of segment s = row off_s + 4i + sub of rows_s).  Per round the first 16 lanes that still have one
-// each put up their lowest survivor; the wave then works lane = pixel: one coalesced 512-byte read per row, the
-// 64 products row[j]*r[j] (rounded to double like the reference's `l*r`) go to LDS, and lane k adds up the
-// products of survivor k in j order -- exactly the reference's `tot += l*r` chain.  A lane's survivors come up in
-// ascending row order, so its strict '>' keeps the first maximum.
-constexpr int kCandRound = 16;
-struct CandLds {
-    double prod[kCandRound * kStageStride];
-    double res[kCandRound];
-};
-
-// LDS hand-off between lanes of ONE wave: DS operations of a wave execute in issue order, so all that is needed is
-// that the compiler keeps the order and the data has landed; no vector-memory wait (a fence would also drain the
-// prefetched global loads)
-__device__ __forceinline__ void wave_lds_sync()
-{
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-}
-
-__device__ __forceinline__ void evaluate_survivors(CandLds& lds, const double* stage, int lane, unsigned mask0, unsigned mask1,
-                                                   int off0, int off1, const double* rows0, const double* rows1, double& v0,
-                                                   int& i0, double& v1, int& i1)
-{
-    const int slot = lane & 15, sub = lane >> 4;
-    v0 = 0.0; v1 = 0.0;
-    i0 = -1; i1 = -1;
-    for (;;) {
-        const bool pending = (mask0 | mask1) != 0;
-        const unsigned long long votes = __ballot(pending);
-        if (!votes) break;
-        const int rank = __popcll(votes & ((1ULL << lane) - 1ULL));
-        const bool active = pending && rank < kCandRound;
-        int seg = 0, a = 0;
-        unsigned long long row_addr = 0;
-        if (active) {
-            if (mask0) { const int i = __builtin_ctz(mask0); mask0 &= mask0 - 1; a = off0 + 4 * i + sub; }
-            else { const int i = __builtin_ctz(mask1); mask1 &= mask1 - 1; a = off1 + 4 * i + sub; seg = 1; }
-            row_addr = (unsigned long long)(uintptr_t)((seg ? rows1 : rows0) + (long long)a * N);
-        }
-        int n = __popcll(votes);
-        if (n > kCandRound) n = kCandRound;
-        unsigned long long left = votes;
-        for (int k0 = 0; k0 < n; k0 += 4) {                     // four row reads in flight; slots past n repeat the last row
-            double x[4], y[4];
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const int src = __builtin_ctzll(left);         // wave-uniform: the lane that put up survivor k0 + kk
-                if (left & (left - 1)) left &= left - 1;
-                const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)row_addr, src);
-                const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(row_addr >> 32), src);
-                const double* row = (const double*)(uintptr_t)(((unsigned long long)hi << 32) | lo);
-                x[kk] = row[lane];
-                y[kk] = stage[(src & 15) * kStageStride + lane];
-            }
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) lds.prod[(k0 + kk) * kStageStride + lane] = x[kk] * y[kk];
-        }
-        wave_lds_sync();
-        if (lane < n) {
-            const double* pr = lds.prod + lane * kStageStride;
-            double tot = 0.0;
-#pragma unroll
-            for (int j = 0; j < N; ++j) tot += pr[j];
-            lds.res[lane] = tot;
-        }
-        wave_lds_sync();
-        if (active) {
-            const double p = lds.res[rank];
-            if (seg == 0) { if (__builtin_fabs(p) > __builtin_fabs(v0)) { v0 = p; i0 = a; } }
-            else if (__builtin_fabs(p) > __builtin_fabs(v1)) { v1 = p; i1 = a; }
-        }
-        wave_lds_sync();
-    }
-    (void)slot;
-}
-
-}  // namespace
-
-// What the filter kernels touch, and nothing else: passing the whole Workspace / DictDevice keeps ~100 SGPRs of
-// pointers alive and spills them into VGPR lanes.
-struct FilterArgs {
-    const unsigned* counters_in;     // ws.counters
-    unsigned* counters_out;          // same array (next step's active counts are reset here)
-    const int* act[3];               // this step's active lists
-    double* r;
-    const double* upd_coeff;         // the previous step's pending residual update (0 = none): r -= coeff * atom
-    const int* upd_sel;              // ~index of a base atom, row of `detail` (this channel) otherwise
-    const int* nblk;
-    double* part_val;
-    int* part_idx;
-    double* cand0_val;
-    int* cand0_row;
-    float* approx_max;               // out: largest approximation over base + block 0, per tile-channel
-    const double* base;              // dictionary, double
-    const double* block0[3];         // DetailBasis[0] of each channel, double
-    const uint16_t* base_f32;        // filter copies
-    const uint16_t* block0_f32[3];
-    int num_base, rows0;
-};
-
-struct DetailFilterArgs {
-    const unsigned* counters;
-    const int* chunks;
-    const int* items;
-    const double* r;
-    double* cand_val;
-    int* cand_row;
-    const float* approx_max;         // written by mp_filter_wave_kernel earlier in the step
-    const double* detail;            // [3][detail_rows][64]
-    long long detail_rows;
-    const uint16_t* detail_f32;
-    const int32_t* block_rows;
-    const int32_t* block_row_off;
-    int num_base;
-};
-
-// --------------------------------------------------------------------------------------------------
-// Wave-autonomous filter kernels.  With the approximations on the bf16 matrix cores the MFMAs are cheap, and what
-// is left of a filtered sweep is memory latency and synchronisation.  So one WAVE takes up to 64 tile-channels (four
-// column groups of 16) and keeps everything in registers: the B operands are read straight from the residual rows,
-// pass 1 runs all row tiles through the MFMAs and only keeps each lane's running maximum, pass 2 runs them again and
-// compares against the threshold, queueing the few survivors for the cooperative exact evaluation.  No workgroup
-// barrier, no LDS besides the 8 KiB product buffer; each dictionary tile read serves up to 64 tile-channels.
-// --------------------------------------------------------------------------------------------------
-namespace {
-
-// B operand of one column group read from global memory: this lane's slot row, elements 32kk + 8h + j
-__device__ __forceinline__ double load_b_global(bf16x8 (&hi)[2], bf16x8 (&lo)[2], double* row, const double* atom, double coeff,
-                                                int lane, bool& nonzero)
-{
-    double2* dst = (double2*)(row + 8 * (lane >> 4));
-    double2 v[8];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int j2 = 0; j2 < 4; ++j2) v[4 * kk + j2] = dst[16 * kk + j2];
-    if (coeff != 0.0) {
-        // the residual update the finish kernel decided on (Vector::Scale then Vector::Subtract, mathvector.cpp:116-148:
-        // two roundings), applied to this lane's 16 elements on their way in and written back for the detail sweep,
-        // the exact evaluations and the next step
-        const double2* src = (const double2*)(atom + 8 * (lane >> 4));
-        double2 a[8];
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int j2 = 0; j2 < 4; ++j2) a[4 * kk + j2] = src[16 * kk + j2];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const double sx = coeff * a[i].x, sy = coeff * a[i].y;
-            v[i].x = v[i].x - sx;
-            v[i].y = v[i].y - sy;
-        }
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int j2 = 0; j2 < 4; ++j2) dst[16 * kk + j2] = v[4 * kk + j2];
-    }
-    double ss = 0.0;
-    bool nzl = false;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const double d = (j & 1) ? v[4 * kk + (j >> 1)].y : v[4 * kk + (j >> 1)].x;
-            nzl = nzl || (d != 0.0);
-            const float x = (float)d;
-            ss += (double)x * (double)x;
-            const unsigned h = bf16_bits(x);
-            const unsigned l = bf16_bits(x - __uint_as_float(h << 16));
-            hi[kk][j] = (short)h;
-            lo[kk][j] = (short)l;
-        }
-    ss += __shfl_xor(ss, 16);
-    ss += __shfl_xor(ss, 32);
-    int nzi = nzl ? 1 : 0;
-    nzi |= __shfl_xor(nzi, 16);
-    nzi |= __shfl_xor(nzi, 32);
-    nonzero = nzi != 0;
-    return ss;
-}
-
-// The two largest approximations a lane has seen among its rows of one segment, and the row of the largest: if the
-// runner-up of the whole tile-channel stays below the threshold, the single survivor is known after pass 1 and the
-// second MFMA pass is not needed for it.
-struct TopTwo {
-    float m1 = 0.0f, m2 = 0.0f;                        // m1 >= m2 throughout
-    float sum = 0.0f;                                  // of every |value| seen: a NaN or an infinity poisons it
-    int row = -1;
-    // five VALU instructions per value (this runs 4 x 576 times per tile-channel group and step): v_cmp + v_cndmask for
-    // the row, v_med3 (the middle of {m1, m2, a} is the new runner-up), v_max, v_add
-    __device__ __forceinline__ void see(float value, int r)
-    {
-        const float a = fabsf(value);
-        row = a > m1 ? r : row;
-        m2 = __builtin_amdgcn_fmed3f(m1, m2, a);
-        m1 = fmaxf(m1, a);
-        sum += a;
-    }
-    // fold in the three other lanes that hold rows of the same tile-channel: top = its largest approximation, second =
-    // its runner-up (a tie for the top counts as a runner-up), mine = this lane owns the unique top row
-    __device__ __forceinline__ void across_lanes(float& top, float& second, bool& mine, bool& any_odd) const
-    {
-        top = fmaxf(m1, __shfl_xor(m1, 16));
-        top = fmaxf(top, __shfl_xor(top, 32));
-        const bool at_top = m1 == top;
-        int n_top = at_top ? 1 : 0;
-        n_top += __shfl_xor(n_top, 16);
-        n_top += __shfl_xor(n_top, 32);
-        float rest = at_top ? m2 : m1;
-        rest = fmaxf(rest, __shfl_xor(rest, 16));
-        rest = fmaxf(rest, __shfl_xor(rest, 32));
-        second = n_top > 1 ? top : rest;
-        mine = at_top && n_top == 1;
-        int o = !(sum <= 3.4028234663852886e38f) ? 1 : 0;          // saw a NaN or an infinity (or overflowed): leave it to pass 2
-        o |= __shfl_xor(o, 16);
-        o |= __shfl_xor(o, 32);
-        any_odd = o != 0;
-    }
-};
-
-// Per-lane FIFO of surviving rows waiting for their exact evaluation.  code = group << 12 | segment << 11 | row.
-struct SurvivorQueue {
-    int q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0;
-    int count = 0;
-    static constexpr int kCapacity = 6;
-    __device__ __forceinline__ void push(int code)
-    {
-        if (count == 0) q0 = code; else if (count == 1) q1 = code; else if (count == 2) q2 = code;
-        else if (count == 3) q3 = code; else if (count == 4) q4 = code; else q5 = code;
-        ++count;
-    }
-    __device__ __forceinline__ int pop()
-    {
-        const int head = q0;
-        q0 = q1; q1 = q2; q2 = q3; q3 = q4; q4 = q5;
-        --count;
-        return head;
-    }
-};
-
-// Best exact projection seen so far by this lane, per column group and segment (0 = base rows | the block, 1 = block 0)
-struct LaneBest {
-    double v[4][2];
-    int i[4][2];
-};
-
-// Drain the queues: rounds of up to 16 survivors (one per lane that has any), evaluated lane = pixel as in
-// evaluate_survivors; `res0..3` are this lane's residual rows for the four column groups.
-__device__ __forceinline__ void drain_survivors(CandLds& lds, int lane, SurvivorQueue& q, const double* rows_seg0,
-                                                const double* rows_seg1, const double* res0, const double* res1,
-                                                const double* res2, const double* res3, LaneBest& best)
-{
-    for (;;) {
-        const bool pending = q.count > 0;
-        const unsigned long long votes = __ballot(pending);
-        if (!votes) break;
-        const int rank = __popcll(votes & ((1ULL << lane) - 1ULL));
-        const bool active = pending && rank < kCandRound;
-        int code = 0;
-        unsigned long long row_addr = 0, res_addr = 0;
-        if (active) {
-            code = q.pop();
-            const int g = code >> 12;
-            row_addr = (unsigned long long)(uintptr_t)(((code >> 11) & 1 ? rows_seg1 : rows_seg0) + (long long)(code & 0x7FF) * N);
-            res_addr = (unsigned long long)(uintptr_t)(g == 0 ? res0 : (g == 1 ? res1 : (g == 2 ? res2 : res3)));
-        }
-        int n = __popcll(votes);
-        if (n > kCandRound) n = kCandRound;
-        unsigned long long left = votes;
-        for (int k0 = 0; k0 < n; k0 += 8) {                     // eight survivors' reads in flight; slots past n repeat the last
-            double x[8], y[8];
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk) {
-                const int src = __builtin_ctzll(left);         // wave-uniform: the lane that put up survivor k0 + kk
-                if (left & (left - 1)) left &= left - 1;
-                const unsigned rl = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)row_addr, src);
-                const unsigned rh = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(row_addr >> 32), src);
-                const unsigned sl = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)res_addr, src);
-                const unsigned sh = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(res_addr >> 32), src);
-                x[kk] = ((const double*)(uintptr_t)(((unsigned long long)rh << 32) | rl))[lane];
-                y[kk] = ((const double*)(uintptr_t)(((unsigned long long)sh << 32) | sl))[lane];
-            }
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk) lds.prod[(k0 + kk) * kStageStride + lane] = x[kk] * y[kk];
-        }
-        wave_lds_sync();
-        if (lane < n) {
-            const double* pr = lds.prod + lane * kStageStride;
-            double tot = 0.0;
-#pragma unroll
-            for (int j = 0; j < N; ++j) tot += pr[j];
-            lds.res[lane] = tot;
-        }
-        wave_lds_sync();
-        if (active) {
-            const double p = lds.res[rank];
-            const int g = code >> 12, seg = (code >> 11) & 1, row = code & 0x7FF;
-#pragma unroll
-            for (int gg = 0; gg < 4; ++gg)
-#pragma unroll
-                for (int ss = 0; ss < 2; ++ss)
-                    if (g == gg && seg == ss && __builtin_fabs(p) > __builtin_fabs(best.v[gg][ss])) {
-                        best.v[gg][ss] = p;
-                        best.i[gg][ss] = row;
-                    }
-        }
-        wave_lds_sync();
-    }
-}
-
-// f(integral_constant<0>), ..., f(integral_constant<COUNT-1>): a loop the optimiser cannot decline to unroll (register
-// arrays indexed by a loop variable that survives as a variable end up in scratch memory)
-template <int COUNT, class F>
-__device__ __forceinline__ void static_for(F&& f)
-{
-    if constexpr (COUNT > 0) {
-        static_for<COUNT - 1>(f);
-        f(std::integral_constant<int, COUNT - 1>{});
-    }
-}
-
-// Run body(tile, operands) over tiles first..last-1 with DEPTH tile reads (4 x 16 B per lane each) in flight ahead of
-// the MFMAs.  DEPTH 1 for large batches (four column groups per wave keep the matrix cores busy and the registers
-// full); DEPTH 4 for small ones, where a tile's MFMAs are far shorter than its L2 round trip.  last - first is a
-// multiple of 4.
-template <int DEPTH, class Ptr, class Body>
-__device__ __forceinline__ void for_each_tile(int first, int last, Ptr&& tile_ptr, Body&& body)
-{
-#define MPC_LOAD_TILE(dst_, tile_)                                                                             \
-    {                                                                                                          \
-        const uint4* p_ = tile_ptr((tile_) < last ? (tile_) : last - 1);                                       \
-        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) dst_[q_] = p_[q_ * 64];                               \
-    }
-    if constexpr (DEPTH == 1) {
-        uint4 a[4], nxt[4];
-        MPC_LOAD_TILE(a, first)
-        for (int tile = first; tile < last; ++tile) {
-            MPC_LOAD_TILE(nxt, tile + 1)
-            body(tile, a);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) a[q] = nxt[q];
-        }
-    } else {
-        static_assert(DEPTH == 4, "ring of four named buffers");
-        uint4 r0[4], r1[4], r2[4], r3[4];
-        MPC_LOAD_TILE(r0, first + 0)
-        MPC_LOAD_TILE(r1, first + 1)
-        MPC_LOAD_TILE(r2, first + 2)
-        MPC_LOAD_TILE(r3, first + 3)
-        for (int t0 = first; t0 < last; t0 += 4) {
-            body(t0 + 0, r0);
-            MPC_LOAD_TILE(r0, t0 + 4)
-            body(t0 + 1, r1);
-            MPC_LOAD_TILE(r1, t0 + 5)
-            body(t0 + 2, r2);
-            MPC_LOAD_TILE(r2, t0 + 6)
-            body(t0 + 3, r3);
-            MPC_LOAD_TILE(r3, t0 + 7)
-        }
-    }
-#undef MPC_LOAD_TILE
-}
-
-}  // namespace
-
-// Base rows and (steps > 0) DetailBasis[0] for up to 64 tile-channels of one channel's active list per wave.
-#ifndef MPC_WAVE_OCC
-#define MPC_WAVE_OCC 2
-#endif
-template <int MAXG, int DEPTH>
-__global__ __launch_bounds__(64, MPC_WAVE_OCC) void mp_filter_wave_kernel(const FilterArgs fa, int cur, int with_detail0, int force_groups)
-{
-    __shared__ CandLds s_cand;
-    const int lane = threadIdx.x;
-    const int slot = lane & 15, sub = lane >> 4;
-    if (blockIdx.x == 0 && lane < 3) fa.counters_out[(cur ^ 1) * 3 + lane] = 0;      // next step's active counts
-    const int n0 = (int)scalar_counter(fa.counters_in, cur * 3 + 0), n1 = (int)scalar_counter(fa.counters_in, cur * 3 + 1),
-              n2 = (int)scalar_counter(fa.counters_in, cur * 3 + 2);
-    // column groups per wave: as many as it takes to give every wave of the grid about one unit (small batches are
-    // latency-bound: spread them thin; large ones amortise each dictionary tile read over 64 tile-channels)
-    int groups = force_groups > 0 ? force_groups : (n0 + n1 + n2 + 16 * (int)gridDim.x - 1) / (16 * (int)gridDim.x);
-    groups = __builtin_amdgcn_readfirstlane(groups < 1 ? 1 : (groups > MAXG ? MAXG : groups));
-    const int per_unit = 16 * groups;
-    const int g0 = (n0 + per_unit - 1) / per_unit, g1 = (n1 + per_unit - 1) / per_unit, g2 = (n2 + per_unit - 1) / per_unit;
-    const int ntiles = kBaseFilterTiles + (with_detail0 ? kBlockFilterTiles : 0);
-    for (int u = blockIdx.x; u < g0 + g1 + g2; u += gridDim.x) {
-        const int ch = __builtin_amdgcn_readfirstlane(u < g0 ? 0 : (u < g0 + g1 ? 1 : 2));
-        const int first = (u - (ch == 0 ? 0 : (ch == 1 ? g0 : g0 + g1))) * per_unit;
-        const int n_act = ch == 0 ? n0 : (ch == 1 ? n1 : n2);
-        const int* act = ch == 0 ? fa.act[0] : (ch == 1 ? fa.act[1] : fa.act[2]);
-        const uint16_t* tiles0 = ch == 0 ? fa.block0_f32[0] : (ch == 1 ? fa.block0_f32[1] : fa.block0_f32[2]);
-        const double* block0 = ch == 0 ? fa.block0[0] : (ch == 1 ? fa.block0[1] : fa.block0[2]);
-
-        int tc[4] = {0, 0, 0, 0};
-        bool ok[4] = {false, false, false, false};
-#pragma unroll
-        for (int g = 0; g < MAXG; ++g) {
-            const int pos = first + 16 * g + slot;
-            ok[g] = g < groups && pos < n_act;
-            tc[g] = act[ok[g] ? pos : first];
-        }
-        bf16x8 bh[4][2], bl[4][2];
-        float window[4];
-        bool live[4], has0[4];
-#pragma unroll
-        for (int g = 0; g < MAXG; ++g) {
-            window[g] = 0.0f; live[g] = false; has0[g] = false;
-            if (g < groups) {
-                bool nz;
-                const double coeff = (with_detail0 && ok[g]) ? fa.upd_coeff[tc[g]] : 0.0;       // steps > 0 only
-                const int sel = (with_detail0 && ok[g]) ? fa.upd_sel[tc[g]] : 0;
-                const double* atom = sel < 0 ? fa.base + (long long)(~sel) * N : block0 + (long long)sel * N;
-                const double ss = load_b_global(bh[g], bl[g], fa.r + (long long)tc[g] * N, atom, coeff, lane, nz);
-                window[g] = 2.0f * (kFilterSlack * (float)__builtin_sqrt(ss) + kFilterAbs);
-                live[g] = ok[g] && nz;                          // an all-zero residual projects to 0 everywhere: index -1
-                has0[g] = with_detail0 && ok[g] && nblk_has0(fa.nblk[tc[g]]);
-            }
-        }
-        __threadfence_block();                                  // the updated residuals are read back lane = pixel below
-        auto tile_ptr = [&](int tile) {
-            return (const uint4*)(tile < kBaseFilterTiles ? fa.base_f32 + tile * 2048 : tiles0 + (tile - kBaseFilterTiles) * 2048) + lane;
-        };
-
-        // ---- pass 1: the two largest approximations per lane (its rows: 16*tile + 4*sub + v), base rows and block 0 apart
-        TopTwo tb[4], td[4];
-        for_each_tile<DEPTH>(0, kBaseFilterTiles, tile_ptr, [&](int tile, const uint4 (&a)[4]) {
-            const int row0 = tile * 16 + sub * 4;
-            static_for<MAXG>([&](auto gc) {
-                constexpr int g = decltype(gc)::value;
-                if (g < groups) {
-                    const f32x4 acc = filter_tile_mfma(a, bh[g], bl[g]);
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) tb[g].see(acc[v], row0 + v);
-                }
-            });
-        });
-        if (with_detail0)
-            for_each_tile<DEPTH>(kBaseFilterTiles, kBaseFilterTiles + kBlockFilterTiles, tile_ptr, [&](int tile, const uint4 (&a)[4]) {
-                const int row0 = (tile - kBaseFilterTiles) * 16 + sub * 4;
-                static_for<MAXG>([&](auto gc) {
-                    constexpr int g = decltype(gc)::value;
-                    if (g < groups) {
-                        const f32x4 acc = filter_tile_mfma(a, bh[g], bl[g]);
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) td[g].see(acc[v], row0 + v);
-                    }
-                });
-            });
-        // thresholds; where the runner-up is below it the survivors are known already (at most one per segment)
-        LaneBest best;
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int sg = 0; sg < 2; ++sg) { best.v[g][sg] = 0.0; best.i[g][sg] = -1; }
-        const double* res0 = fa.r + (long long)tc[0] * N;
-        const double* res1 = fa.r + (long long)tc[1] * N;
-        const double* res2 = fa.r + (long long)tc[2] * N;
-        const double* res3 = fa.r + (long long)tc[3] * N;
-        float thr[4];
-        bool second_pass[4] = {false, false, false, false};    // wave-uniform per column group
-        SurvivorQueue queue;
-        static_for<MAXG>([&](auto gc) {
-            constexpr int g = decltype(gc)::value;
-            float top_b, second_b, top_d, second_d;
-            bool mine_b, mine_d, odd_b, odd_d;
-            tb[g].across_lanes(top_b, second_b, mine_b, odd_b);
-            td[g].across_lanes(top_d, second_d, mine_d, odd_d);
-            const float top = has0[g] ? fmaxf(top_b, top_d) : top_b;      // one threshold for base rows and block 0
-            thr[g] = top - window[g];
-            if (sub == 0 && ok[g]) fa.approx_max[tc[g]] = top;
-            // ambiguous: a runner-up at or above the threshold, a non-positive threshold (zero pads would qualify), NaN/Inf
-            const bool unclear = !(second_b < thr[g]) || (has0[g] && !(second_d < thr[g])) || !(thr[g] > 0.0f) || odd_b ||
-                                 (has0[g] && odd_d);
-            second_pass[g] = g < groups && __ballot(live[g] && unclear) != 0;
-            if (g < groups && !second_pass[g] && live[g]) {
-                if (mine_b && !(top_b < thr[g])) queue.push((g << 12) | tb[g].row);
-                if (has0[g] && mine_d && !(top_d < thr[g])) queue.push((g << 12) | 0x800 | td[g].row);
-            }
-            if (__ballot(queue.count > SurvivorQueue::kCapacity - 2))       // room for the next group's two
-                drain_survivors(s_cand, lane, queue, fa.base, block0, res0, res1, res2, res3, best);
-        });
-
-        // ---- pass 2, only for column groups with an unclear tile-channel: the same MFMAs again; rows at or above the
-        //      threshold queue up for exact evaluation
-        // pass 2 pushes up to four rows of a lane per tile before it looks at the fill level: enter it with room for them
-        if ((second_pass[0] || second_pass[1] || second_pass[2] || second_pass[3]) &&
-            __ballot(queue.count > SurvivorQueue::kCapacity - 4))
-            drain_survivors(s_cand, lane, queue, fa.base, block0, res0, res1, res2, res3, best);
-        if (second_pass[0] || second_pass[1] || second_pass[2] || second_pass[3])
-            for_each_tile<DEPTH>(0, ntiles, tile_ptr, [&](int tile, const uint4 (&a)[4]) {
-                const bool is_base = tile < kBaseFilterTiles;
-                const int row0 = (is_base ? tile * 16 : (tile - kBaseFilterTiles) * 16) + sub * 4;
-                const int limit = is_base ? fa.num_base : fa.rows0;
-                static_for<MAXG>([&](auto gc) {
-                    constexpr int g = decltype(gc)::value;
-                    if (second_pass[g]) {
-                        const f32x4 acc = filter_tile_mfma(a, bh[g], bl[g]);
-                        const bool wanted = live[g] && (is_base || has0[g]);
-#pragma unroll
-                        for (int v = 0; v < 4; ++v)
-                            if (wanted && !(fabsf(acc[v]) < thr[g]) && row0 + v < limit)
-                                queue.push((g << 12) | (is_base ? 0 : 0x800) | (row0 + v));
-                        if (__ballot(queue.count > SurvivorQueue::kCapacity - 4))
-                            drain_survivors(s_cand, lane, queue, fa.base, block0, res0, res1, res2, res3, best);
-                    }
-                });
-            });
-        drain_survivors(s_cand, lane, queue, fa.base, block0, res0, res1, res2, res3, best);
-
-        // ---- the four lanes of a slot hold interleaved rows: combine by (|value|, lower row), lane sub == 0 reports
-#pragma unroll
-        for (int g = 0; g < MAXG; ++g) {
-            if (g >= groups) continue;
-#pragma unroll
-            for (int sg = 0; sg < 2; ++sg) {
-                keep_better(best.v[g][sg], best.i[g][sg], __shfl_xor(best.v[g][sg], 16), __shfl_xor(best.i[g][sg], 16));
-                keep_better(best.v[g][sg], best.i[g][sg], __shfl_xor(best.v[g][sg], 32), __shfl_xor(best.i[g][sg], 32));
-            }
-            if (sub == 0 && ok[g]) {
-                fa.part_val[(long long)tc[g] * kMaxParts] = best.v[g][0];
-                fa.part_idx[(long long)tc[g] * kMaxParts] = best.i[g][0];
-                if (has0[g]) {
-                    fa.cand0_val[tc[g]] = best.v[g][1];
-                    fa.cand0_row[tc[g]] = best.i[g][1];
-                }
-            }
-        }
-    }
-}
-
 // Row range `part` of `row_parts` of a block with `rows` rows: [lo, hi)
 __device__ __forceinline__ void row_range(int rows, int row_parts, int part, int& lo, int& hi)
 {
@@ -959,96 +334,6 @@ __global__ __launch_bounds__(64, 3) void mp_detail_kernel(const Workspace ws, co
         }
     }
     if (keep == 123456.789) touch_sink[lane] = keep;          // never true: keeps the touch loads alive
-}
-
-// filtered detail sweep: the same filter for the bucketed detail blocks.  One wave per 16 items of a chunk
-// (<= 64 items of one (channel, block) bucket): 64 x 16 approximations (4 tiles, 24 MFMAs), then lane (slot, sub)
-// scans every fourth row of its item and the survivors are evaluated exactly.  16 KiB of LDS per wave.
-__global__ __launch_bounds__(64) void mp_detail_filter_kernel(const DetailFilterArgs da)
-{
-    __shared__ __attribute__((aligned(16))) char s_buf[sizeof(CandLds)];   // approximations [row][slot], then the products
-    static_assert(sizeof(CandLds) >= sizeof(float) * 64 * kFilterGroup, "s_p fits");
-    __shared__ double s_r[kFilterGroup * kStageStride];
-    float* s_p = reinterpret_cast<float*>(s_buf);
-    CandLds& s_cand = *reinterpret_cast<CandLds*>(s_buf);
-    const int lane = threadIdx.x;
-    const int slot = lane & 15, sub = lane >> 4;
-    const unsigned n_units = scalar_counter(da.counters, 7) * 4u;
-    // Workgroups are dealt to the eight XCDs round-robin, and every XCD has an L2 of its own: keep runs of kRun
-    // consecutive units -- the quarters of a chunk and the next chunks of the same bucket, which read the same four
-    // tiles of a 24.6 MB table -- on one XCD instead of spreading each over eight caches.
-    constexpr unsigned kRun = 16;
-    const unsigned padded = (n_units + 8 * kRun - 1) / (8 * kRun) * (8 * kRun);
-    for (unsigned v = blockIdx.x; v < padded; v += gridDim.x) {
-        const unsigned xcd = v & 7u, j = v >> 3;
-        const unsigned u = ((j / kRun) * 8u + xcd) * kRun + (j % kRun);
-        if (u >= n_units) continue;
-        const int* desc = da.chunks + 4 * (long long)(u >> 2);
-        const int bucket = __builtin_amdgcn_readfirstlane(desc[0]);
-        const int begin = __builtin_amdgcn_readfirstlane(desc[1]) + 16 * (int)(u & 3);
-        const int cnt = __builtin_amdgcn_readfirstlane(desc[2]) - begin;       // items of this wave (may be <= 0)
-        if (cnt <= 0) continue;
-        const int ch = bucket >> 9, blk = bucket & 511;
-        const int my_tc = da.items[begin + (slot < cnt ? slot : 0)];
-        // the block's four filter tiles: issued before anything waits, consumed after the residuals are staged
-        const uint4* tiles = (const uint4*)(da.detail_f32 + ((long long)ch * da.num_base + blk) * kBlockFilterTiles * 2048);
-        uint4 av[kBlockFilterTiles][4];
-#pragma unroll
-        for (int tile = 0; tile < kBlockFilterTiles; ++tile)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) av[tile][q] = tiles[(tile * 4 + q) * 64 + lane];
-        const int rows = __builtin_amdgcn_readfirstlane(da.block_rows[blk]);
-        double rv[kFilterGroup];
-#pragma unroll
-        for (int i = 0; i < kFilterGroup; ++i) rv[i] = da.r[(long long)__builtin_amdgcn_readlane(my_tc, i) * N + lane];
-        bool nz = false;
-#pragma unroll
-        for (int i = 0; i < kFilterGroup; ++i) {
-            s_r[i * kStageStride + lane] = rv[i];
-            const bool any = __ballot(rv[i] != 0.0) != 0;
-            if (slot == i) nz = any;
-        }
-        __syncthreads();
-        bf16x8 r_hi[2], r_lo[2];
-        const double ss = load_b_operand(r_hi, r_lo, s_r, lane);
-        const float window = 2.0f * (kFilterSlack * (float)__builtin_sqrt(ss) + kFilterAbs);
-#pragma unroll
-        for (int tile = 0; tile < kBlockFilterTiles; ++tile) {
-            const f32x4 acc = filter_tile_mfma(av[tile], r_hi, r_lo);
-#pragma unroll
-            for (int v = 0; v < 4; ++v) s_p[(tile * 16 + sub * 4 + v) * kFilterGroup + slot] = acc[v];
-        }
-        __syncthreads();
-        float pv[16];
-        float mx = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            pv[i] = fabsf(s_p[(4 * i + sub) * kFilterGroup + slot]);
-            mx = fmaxf(mx, pv[i]);
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float thr = fmaxf(mx, da.approx_max[my_tc]) - window;      // a row far below the base maximum cannot win
-        __syncthreads();                                         // s_p is dead from here: its space takes the products
-        unsigned mask = 0;
-        if (slot < cnt && nz) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i)
-                if (!(pv[i] < thr)) mask |= 1u << i;
-            mask &= low_bits((rows - sub + 3) >> 2);
-        }
-        double best_val, unused_val;
-        int best_row, unused_row;
-        const double* block = da.detail + ((long long)ch * da.detail_rows + __builtin_amdgcn_readfirstlane(da.block_row_off[blk])) * N;
-        evaluate_survivors(s_cand, s_r, lane, mask, 0u, 0, 0, block, block, best_val, best_row, unused_val, unused_row);
-        keep_better(best_val, best_row, __shfl_xor(best_val, 16), __shfl_xor(best_row, 16));
-        keep_better(best_val, best_row, __shfl_xor(best_val, 32), __shfl_xor(best_row, 32));
-        if (sub == 0 && slot < cnt) {
-            da.cand_val[(long long)(begin + slot) * kMaxRowParts] = best_val;
-            da.cand_row[(long long)(begin + slot) * kMaxRowParts] = best_row;
-        }
-        __syncthreads();
-    }
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -1546,33 +831,6 @@ size_t workspace_bytes(int cap, int K)
 
 Workspace carve_workspace(void* device_mem, int cap, int K) { return carve(static_cast<char*>(device_mem), cap, K, nullptr); }
 
-namespace {
-FilterArgs filter_args(const Workspace& ws, const DictDevice& dict, int cur)
-{
-    FilterArgs fa{};
-    fa.counters_in = ws.counters;
-    fa.counters_out = ws.counters;
-    for (int ch = 0; ch < 3; ++ch) {
-        fa.act[ch] = ws.act[cur][ch];
-        fa.block0[ch] = dict.detail + (long long)ch * dict.detail_rows * N;
-        fa.block0_f32[ch] = dict.detail_f32 + (long long)ch * dict.num_base * kBlockFilterTiles * 2048;
-    }
-    fa.r = ws.r;
-    fa.upd_coeff = ws.upd_coeff;
-    fa.upd_sel = ws.upd_sel;
-    fa.nblk = ws.nblk;
-    fa.part_val = ws.part_val;
-    fa.part_idx = ws.part_idx;
-    fa.cand0_val = ws.cand0_val;
-    fa.cand0_row = ws.cand0_row;
-    fa.approx_max = ws.approx_max;
-    fa.base = dict.base;
-    fa.base_f32 = dict.base_f32;
-    fa.num_base = dict.num_base;
-    fa.rows0 = dict.block0_rows;
-    return fa;
-}
-}  // namespace
 
 // Final residual energies (Outputs::energy, a diagnostic the reference does not compute), once per batch after the last
 // step.  A wave takes 16 tile-channels: lane = pixel for coalesced reads of the residual rows, eight rows in flight (and
@@ -1625,27 +883,11 @@ int enqueue_pursuit(const DictDevice& dict, const Workspace& ws, const FrameInpu
                     const double* quant_dev, int K, long long tc_begin, int n, int parts, int row_parts, int sweep_waves,
                     void* stream_, void** base_events, void* side_stream_, void* fork_event_, void* join_event_)
 {
-    DetailFilterArgs detail_args{};
-    detail_args.counters = ws.counters;
-    detail_args.chunks = ws.chunks;
-    detail_args.items = ws.items;
-    detail_args.r = ws.r;
-    detail_args.cand_val = ws.cand_val;
-    detail_args.cand_row = ws.cand_row;
-    detail_args.approx_max = ws.approx_max;
-    detail_args.detail = dict.detail;
-    detail_args.detail_rows = dict.detail_rows;
-    detail_args.detail_f32 = dict.detail_f32;
-    detail_args.block_rows = dict.block_rows;
-    detail_args.block_row_off = dict.block_row_off;
-    detail_args.num_base = dict.num_base;
     hipStream_t s = static_cast<hipStream_t>(stream_);
     hipStream_t side = static_cast<hipStream_t>(side_stream_);
     hipEvent_t ev_fork = static_cast<hipEvent_t>(fork_event_), ev_join = static_cast<hipEvent_t>(join_event_);
     const bool forked = side != nullptr && ev_fork != nullptr && ev_join != nullptr;
     if (n < 1 || n > ws.cap) return (int)hipErrorInvalidValue;
-    const bool filtered = parts < 1;          // sweeps through the MFMA filter instead of correlating every row exactly
-    if (filtered) row_parts = 1;
     if (parts < 1) parts = 1;
     if (parts > kMaxParts) parts = kMaxParts;
     if (row_parts < 1) row_parts = 1;
@@ -1658,48 +900,31 @@ int enqueue_pursuit(const DictDevice& dict, const Workspace& ws, const FrameInpu
     const unsigned max_slabs = lists * (unsigned)((per_list + 255) / 256);
     const unsigned slots = (unsigned)(sweep_waves > 0 ? sweep_waves : 3072);
     auto clampu = [](unsigned v, unsigned hi) { return v < hi ? (v ? v : 1u) : hi; };
-    // the wave-autonomous filter kernels hold 2 waves per SIMD; experiments: MPC_WAVE_SLOTS, MPC_GROUPS
-    static const unsigned wave_slots = [] { const char* v = std::getenv("MPC_WAVE_SLOTS"); return v && *v ? (unsigned)std::atoi(v) : 2048u; }();
-    // at most two column groups per wave would be used anyway: take the variant that spends its registers on tile reads
-    const bool small_batch = (long long)n <= 2LL * 16 * wave_slots && std::getenv("MPC_NO_SMALL") == nullptr;
-    static const int force_groups = [] { const char* v = std::getenv("MPC_GROUPS"); return v && *v ? std::atoi(v) : 0; }();
     hipLaunchKernelGGL(mp_init_kernel, dim3(clampu((unsigned)((n + 2) / 3), 16384u)), dim3(64), 0, s, ws, in, tc_begin, n);
     for (int step = 0; step < K; ++step) {
         const int cur = step & 1;
         if (step > 0) {
             hipLaunchKernelGGL(mp_fill_kernel, dim3(clampu(max_slabs, 2048u)), dim3(256), 0, s, ws, cur, step & 1);
-            if (forked && !filtered) (void)hipStreamWaitEvent(s, ev_join, 0);   // the previous step's residual update
+            if (forked) (void)hipStreamWaitEvent(s, ev_join, 0);   // the previous step's residual update
         }
         if (base_events) (void)hipEventRecord(static_cast<hipEvent_t>(base_events[2 * step]), s);
-        if (filtered)
-            if (small_batch)
-                hipLaunchKernelGGL((mp_filter_wave_kernel<2, 4>), dim3(clampu(lists * (unsigned)((per_list + 15) / 16), wave_slots)), dim3(64),
-                                   0, s, filter_args(ws, dict, cur), cur, step > 0 ? 1 : 0, force_groups);
-            else
-                hipLaunchKernelGGL((mp_filter_wave_kernel<4, 1>), dim3(clampu(lists * (unsigned)((per_list + 15) / 16), wave_slots)), dim3(64),
-                                   0, s, filter_args(ws, dict, cur), cur, step > 0 ? 1 : 0, force_groups);
-        else
-            hipLaunchKernelGGL(mp_base_kernel, dim3(clampu(max_groups * (unsigned)(parts + 1), slots)), dim3(64), 0, s, ws, dict,
-                               cur, parts, step > 0 ? 1 : 0, (int)slots);
+        hipLaunchKernelGGL(mp_base_kernel, dim3(clampu(max_groups * (unsigned)(parts + 1), slots)), dim3(64), 0, s, ws, dict,
+                           cur, parts, step > 0 ? 1 : 0, (int)slots);
         if (base_events) (void)hipEventRecord(static_cast<hipEvent_t>(base_events[2 * step + 1]), s);
-        if (step > 0) {
-            if (filtered)
-                hipLaunchKernelGGL(mp_detail_filter_kernel, dim3(clampu(max_groups * 4u, 3072u)), dim3(64), 0, s, detail_args);
-            else
-                hipLaunchKernelGGL(mp_detail_kernel, dim3(clampu(max_groups * (unsigned)row_parts, slots)), dim3(64), 0, s, ws,
-                                   dict, row_parts, (int)slots, ws.cand_val);
-        }
+        if (step > 0)
+            hipLaunchKernelGGL(mp_detail_kernel, dim3(clampu(max_groups * (unsigned)row_parts, slots)), dim3(64), 0, s, ws,
+                               dict, row_parts, (int)slots, ws.cand_val);
         hipLaunchKernelGGL(mp_finish_kernel, dim3(clampu(max_slabs, 2048u)), dim3(256), 0, s, ws, dict, out, quant_dev, K,
                            step, cur, parts, row_parts, (int)slots);
         if (step + 1 < K) {
             // The residual update and the next step's bucket + fill only depend on the finish kernel, not on each other:
             // with a side stream the update runs beside them and is joined in front of the next sweep.
-            if (forked && !filtered) {
+            if (forked) {
                 (void)hipEventRecord(ev_fork, s);
                 (void)hipStreamWaitEvent(side, ev_fork, 0);
                 hipLaunchKernelGGL(mp_update_kernel, dim3(clampu(max_groups, 4096u)), dim3(64), 0, side, ws, dict, cur);
                 (void)hipEventRecord(ev_join, side);
-            } else if (!filtered) {                               // the filter kernel applies the update as it reads the residuals
+            } else {
                 hipLaunchKernelGGL(mp_update_kernel, dim3(clampu(max_groups, 4096u)), dim3(64), 0, s, ws, dict, cur);
             }
         }

@@ -173,6 +173,10 @@ struct TopKeys {
     __device__ __forceinline__ void see(unsigned value_bits, unsigned keep_mask, unsigned code)
     {
         const unsigned key = (value_bits & keep_mask) | code;
+        see_key(key);
+    }
+    __device__ __forceinline__ void see_key(unsigned key)
+    {
         k2 = __builtin_amdgcn_fmed3f(k1, k2, __uint_as_float(key));
         const unsigned k1b = __float_as_uint(k1);
         k1 = __uint_as_float(k1b > key ? k1b : key);
@@ -266,7 +270,9 @@ __device__ __forceinline__ void keep_better(T& v, int& i, int& sel, T ov, int oi
 #ifdef MPC_STAMPS
 #define STAMP(i)                                              \
     {                                                         \
+        __builtin_amdgcn_sched_barrier(0);                    \
         const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        __builtin_amdgcn_sched_barrier(0);                    \
         stamp_acc[i] += now_ - stamp_prev;                    \
         stamp_prev = now_;                                    \
     }
@@ -390,6 +396,66 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
         for (int q = 0; q < 4; ++q) dst[q] = tiles[t * 256 + q * 64];
     };
 
+    // ---- pairs: P_b -= float(c) * G[a][b] for the atom a chosen by the step just finished; top two upper bounds |P_b| + E as
+    //      keys.  The update of a step's pairs needs only that step's choice (atom, coefficient), not the updated residual:
+    //      it runs at the END of the step, between the request for the chosen row and the residual update that waits for it,
+    //      and its results (tp, lbmax, oddp) are used by the next step's thresholds.  rbound = |r~| of the residual BEFORE the
+    //      update bounds the updated one as well (an MP step with a non-zero quantised coefficient does not lengthen it, up
+    //      to rounding covered by the 1.0000002 in it): a valid, marginally wider E.
+    TopKeys tp[kGroups];
+    float lbmax[kGroups];
+    bool oddp[kGroups];
+    float rbound[kGroups];
+#pragma unroll
+    for (int g = 0; g < kGroups; ++g) { lbmax[g] = -3.0e38f; oddp[g] = false; rbound[g] = 0.0f; }
+    // same_p: p is the same in every lane (a loop counter): every key's code then sits in a scalar register of its own
+    auto pair_update = [&](auto gc, auto same_p, int p, bool upd, unsigned info, float4 (&pv)[4], const float4 (&gv)[4], float E) {
+        constexpr int g = decltype(gc)::value;
+        const long long pi = (long long)(g * 16 + slot) * kMaxPairs + p;
+        const int rows = (int)((info >> 9) & 127u);
+        if (upd) {
+            const float c32 = (float)tc[g].coeff;
+            float4* pp = reinterpret_cast<float4*>(my_p + pi * 64 + 4 * h);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                pv[t].x = fmaf(-c32, gv[t].x, pv[t].x);
+                pv[t].y = fmaf(-c32, gv[t].y, pv[t].y);
+                pv[t].z = fmaf(-c32, gv[t].z, pv[t].z);
+                pv[t].w = fmaf(-c32, gv[t].w, pv[t].w);
+                pp[4 * t] = pv[t];
+            }
+            // |P_b - <b, r>| grows by at most 2^-23 |c| (rounding of c and of G) + 2^-24 (|r| + E) (the fma's result)
+            E = (E + 0x1p-21f * (fabsf(c32) + rbound[g])) * 1.000001f;
+            if (h == 0) my_e[pi] = E;
+            oddp[g] = oddp[g] || !(fabsf(c32) < kHuge);
+        }
+        oddp[g] = oddp[g] || !(E < kHuge);
+        // The pair's two largest |P| of this lane first, as keys (the mask clears the sign; the code names tile and value), E added
+        // to those two only (it is the same for all 64 rows), then merged into the slot's keys with the pair's number in the code.
+        // A key's value part is <= |P| and >= |P| (1 - 2^-14); adding E and cutting again loses as much once more: the threshold
+        // on pair keys is lowered by 2^-12 (thresholds below).  Rows 62 and 63 of a block can be pads (blocks have 62 or 63 rows):
+        // lane row h = 3, tile 3, v = 2, 3.  Their P and G are exactly 0; their upper bound must be 0 too (not E), or a pad could
+        // pass for a survivor.
+        const bool pad2 = h == 3 && rows < 63, pad3 = h == 3 && rows < 64;
+        const unsigned keepp = keep_pair_mask;
+        TopKeys lk;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float vals[4] = {pv[t].x, pv[t].y, pv[t].z, pv[t].w};
+#pragma unroll
+            for (int v = 0; v < 4; ++v) lk.see(__float_as_uint(vals[v]), keepp, (unsigned)((t << 2) | v));
+        }
+        const unsigned pcode = decltype(same_p)::value ? in_sgpr((unsigned)__builtin_amdgcn_readfirstlane(p << 4)) : (unsigned)(p << 4);
+        auto bounded = [&](float key) {                              // the key of (|P| + E) with the pair's number in its code
+            const unsigned kb = __float_as_uint(key), code = kb & 15u;
+            float ub = __uint_as_float(kb & kKeepPair) + E;
+            if ((code == 14u && pad2) || (code == 15u && pad3)) ub = 0.0f;
+            return (__float_as_uint(ub) & kKeepPair) | pcode | code;
+        };
+        tp[g].see_key(bounded(lk.k1));
+        tp[g].see_key(bounded(lk.k2));
+        lbmax[g] = __builtin_amdgcn_fmed3f(lbmax[g], __uint_as_float(__float_as_uint(lk.k1) & kKeepPair) - E, __builtin_inff());
+    };
     for (;;) {
         // ---- (1) refill: slots whose tile-channel has ended take the next tile-channels from the queue, kRefillAt or more at
         //      a time (one atomic per refill; a wave whose slots are all free refills at once)
@@ -427,12 +493,26 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
                 const int tx = tile / a.tile_rows, ty = a.tile_row_begin + (tile - tx * a.tile_rows);
                 const uint8_t* img = a.rgb + (long long)frame * a.frame_stride;
                 unsigned char px[16][3];
+                // the lane's 16 pixels are two rows of 8 (24 bytes each, at 24 tx: 8-byte aligned when the rows are).  Whole tiles
+                // of an 8-byte aligned image take them as six 8-byte loads; ragged edges and odd strides byte by byte, clamped
+                const bool whole = tx * 8 + 8 <= a.width && ty * 8 + 8 <= a.height;
+                if (a.rgb_aligned8 && !__ballot(!whole)) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {                      // block index dx + 8 dy = pix0 + i
-                    const int x = tx * 8 + (i & 7), y = ty * 8 + (pix0 >> 3) + (i >> 3);
-                    const int xc = x < a.width ? x : a.width - 1, yc = y < a.height ? y : a.height - 1;
-                    const uint8_t* p = img + (long long)yc * a.row_stride + 3 * xc;
-                    px[i][0] = p[0]; px[i][1] = p[1]; px[i][2] = p[2];
+                    for (int rr = 0; rr < 2; ++rr) {
+                        const uint2* p = reinterpret_cast<const uint2*>(img + (long long)(ty * 8 + (pix0 >> 3) + rr) * a.row_stride + 24 * tx);
+                        const uint2 v0 = p[0], v1 = p[1], v2 = p[2];
+                        const unsigned w[6] = {v0.x, v0.y, v1.x, v1.y, v2.x, v2.y};
+#pragma unroll
+                        for (int b = 0; b < 24; ++b) px[8 * rr + b / 3][b % 3] = (unsigned char)((w[b >> 2] >> (8 * (b & 3))) & 0xFFu);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {                  // block index dx + 8 dy = pix0 + i
+                        const int x = tx * 8 + (i & 7), y = ty * 8 + (pix0 >> 3) + (i >> 3);
+                        const int xc = x < a.width ? x : a.width - 1, yc = y < a.height ? y : a.height - 1;
+                        const uint8_t* p = img + (long long)yc * a.row_stride + 3 * xc;
+                        px[i][0] = p[0]; px[i][1] = p[1]; px[i][2] = p[2];
+                    }
                 }
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
@@ -485,24 +565,6 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
         COUNT(12, 1)
         static_for<kGroups>([&](auto gc) { COUNT(16, __popcll(__ballot(tc[decltype(gc)::value].live && unit[decltype(gc)::value] >= 0))) });
 
-        // ---- (2) the Gram update of pair 0 of both groups needs P, G and E from memory: in flight while the B operands are built
-        float4 pv0[kGroups][4], gv0[kGroups][4];
-        float E0[kGroups];
-        bool on0[kGroups], upd0[kGroups];
-        unsigned info0[kGroups];
-#pragma unroll
-        for (int g = 0; g < kGroups; ++g) {
-            on0[g] = unit[g] >= 0 && tc[g].live && tc[g].npairs > 0 && tc[g].fresh != 0;
-            upd0[g] = on0[g] && tc[g].coeff != 0.0;
-            info0[g] = tc[g].packed(0);
-            const long long pi = (long long)(g * 16 + slot) * kMaxPairs;
-            const float4* pp = reinterpret_cast<const float4*>(my_p + pi * 64 + 4 * h);
-            const float4* gp = reinterpret_cast<const float4*>(gram + (upd0[g] ? (long long)tc[g].sel_g * a.gram_stride + (int)(info0[g] & 511u) * 64 : 0) + 4 * h);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) { pv0[g][t] = pp[4 * t]; gv0[g][t] = gp[4 * t]; }
-            E0[g] = my_e[pi];
-        }
-
         // ---- (2a) B operands from the residuals; error bound of this step's MFMA approximations ----------------------
         bf16x8 bh[kGroups][2], bl[kGroups][2];
         float Eb[kGroups], rnorm[kGroups];
@@ -526,96 +588,10 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
             nz[g] = reduce4_add(nzl ? 1u : 0u) != 0u;
             rnorm[g] = (float)__builtin_sqrt(ss) * 1.0000002f;
             Eb[g] = kSlack * rnorm[g] + kAbs;
+            rbound[g] = rnorm[g];
             odd[g] = !(rnorm[g] < kHuge);                           // NaN, infinity or large enough to overflow the f32 side
         });
         STAMP(1)
-
-        // ---- (2b) pairs: P_b -= float(c) * G[a][b] for the atom a chosen last step; top two upper bounds |P_b| + E as keys
-        TopKeys tp[kGroups];
-        float lbmax[kGroups];
-        bool oddp[kGroups];
-#pragma unroll
-        for (int g = 0; g < kGroups; ++g) { lbmax[g] = -3.0e38f; oddp[g] = false; }
-        // same_p: p is the same in every lane (a loop counter): every key's code then sits in a scalar register of its own
-        auto pair_update = [&](auto gc, auto same_p, int p, bool upd, unsigned info, float4 (&pv)[4], const float4 (&gv)[4], float E) {
-            constexpr int g = decltype(gc)::value;
-            const long long pi = (long long)(g * 16 + slot) * kMaxPairs + p;
-            const int rows = (int)((info >> 9) & 127u);
-            if (upd) {
-                const float c32 = (float)tc[g].coeff;
-                float4* pp = reinterpret_cast<float4*>(my_p + pi * 64 + 4 * h);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    pv[t].x = fmaf(-c32, gv[t].x, pv[t].x);
-                    pv[t].y = fmaf(-c32, gv[t].y, pv[t].y);
-                    pv[t].z = fmaf(-c32, gv[t].z, pv[t].z);
-                    pv[t].w = fmaf(-c32, gv[t].w, pv[t].w);
-                    pp[4 * t] = pv[t];
-                }
-                // |P_b - <b, r>| grows by at most 2^-23 |c| (rounding of c and of G) + 2^-24 (|r| + E) (the fma's result)
-                E = (E + 0x1p-21f * (fabsf(c32) + rnorm[g])) * 1.000001f;
-                if (h == 0) my_e[pi] = E;
-                oddp[g] = oddp[g] || !(fabsf(c32) < kHuge);
-            }
-            oddp[g] = oddp[g] || !(E < kHuge);
-            // rows 62 and 63 of a block can be pads (blocks have 62 or 63 rows): lane row h = 3, tile 3, v = 2, 3.  Their P and G
-            // are exactly 0; their upper bound must be 0 too (not E), or a pad could pass for a survivor.
-            const bool pad2 = h == 3 && rows < 63, pad3 = h == 3 && rows < 64;
-            const unsigned keepp = keep_pair_mask;
-            float biggest = 0.0f;                                   // of this pair's |P|: its lower bound is biggest - E
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float vals[4] = {pv[t].x, pv[t].y, pv[t].z, pv[t].w};
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const float m = fabsf(vals[v]);
-                    float ub = m + E;
-                    if (t == 3 && v == 2) ub = pad2 ? 0.0f : ub;
-                    if (t == 3 && v == 3) ub = pad3 ? 0.0f : ub;
-                    const unsigned code = (unsigned)((p << 4) | (t << 2) | v);
-                    tp[g].see(__float_as_uint(ub), keepp, decltype(same_p)::value ? in_sgpr((unsigned)__builtin_amdgcn_readfirstlane((int)code)) : code);
-                    biggest = __builtin_amdgcn_fmed3f(biggest, m, __builtin_inff());
-                }
-            }
-            lbmax[g] = __builtin_amdgcn_fmed3f(lbmax[g], biggest - E, __builtin_inff());
-        };
-        static_for<kGroups>([&](auto gc) {
-            constexpr int g = decltype(gc)::value;
-            if (__ballot(on0[g])) { COUNT(17, 1) COUNT(18, __popcll(__ballot(on0[g] && h == 0))) }
-            if (on0[g]) pair_update(gc, std::true_type{}, 0, upd0[g], info0[g], pv0[g], gv0[g], E0[g]);
-        });
-#pragma unroll 1
-        for (int p = 1;; ++p) {                                     // further pairs: both groups' loads of a round issued together
-            bool on[kGroups];
-            bool any = false;
-#pragma unroll
-            for (int g = 0; g < kGroups; ++g) {
-                on[g] = unit[g] >= 0 && tc[g].live && p < tc[g].npairs && p != tc[g].fresh;
-                any = any || (unit[g] >= 0 && tc[g].live && p < tc[g].npairs);
-            }
-            if (!__ballot(any)) break;
-            unsigned info[kGroups];
-            float4 pv[kGroups][4], gv[kGroups][4];
-            float E[kGroups];
-            bool upd[kGroups];
-#pragma unroll
-            for (int g = 0; g < kGroups; ++g) {
-                const long long pi = (long long)(g * 16 + slot) * kMaxPairs + (on[g] ? p : 0);
-                info[g] = p < 4 ? tc[g].packed(p) : (my_meta[2 * pi] & 0xFFFFu);
-                upd[g] = on[g] && tc[g].coeff != 0.0;
-                const float4* pp = reinterpret_cast<const float4*>(my_p + pi * 64 + 4 * h);
-                const float4* gp = reinterpret_cast<const float4*>(gram + (upd[g] ? (long long)tc[g].sel_g * a.gram_stride + (int)(info[g] & 511u) * 64 : 0) + 4 * h);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) { pv[g][t] = pp[4 * t]; gv[g][t] = gp[4 * t]; }
-                E[g] = my_e[pi];
-            }
-            static_for<kGroups>([&](auto gc) {
-                constexpr int g = decltype(gc)::value;
-                COUNT(17, 1) COUNT(18, __popcll(__ballot(on[g] && h == 0)))
-                if (on[g]) pair_update(gc, std::true_type{}, p, upd[g], info[g], pv[g], gv[g], E[g]);
-            });
-        }
-        STAMP(2)
 
         // ---- (2c) a pair created by the last step: first approximations of its 64 rows from the block's filter tiles (their
         //      lines were pulled towards the cache when the pair was created)
@@ -711,25 +687,14 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
             for (int g = 0; g < kGroups; ++g) acc[g] = tile_mfma(tbuf, bh[g], bl[g]);
             track(tb, prev, 4 * (kBaseFilterTiles - 2));
             track(tb, acc, 4 * (kBaseFilterTiles - 1));
-            if (any0 && home) {
+            if (any0) {
 #pragma unroll 1
                 for (int t = 0; t < kBlockFilterTiles; ++t) {
-                    lds_tile(ta, kBaseFilterTiles + t);
+                    if (home) lds_tile(ta, kBaseFilterTiles + t);
+                    else far_tile(ta, t);
 #pragma unroll
                     for (int g = 0; g < kGroups; ++g) acc[g] = tile_mfma(ta, bh[g], bl[g]);
                     track(td, acc, 4 * t);
-                }
-            } else if (any0) {                                      // two tiles in flight, like a new pair's
-#pragma unroll
-                for (int t = 0; t < kBlockFilterTiles; t += 2) {
-                    far_tile(ta, t);
-                    far_tile(tbuf, t + 1);
-#pragma unroll
-                    for (int g = 0; g < kGroups; ++g) acc[g] = tile_mfma(ta, bh[g], bl[g]);
-                    track(td, acc, 4 * t);
-#pragma unroll
-                    for (int g = 0; g < kGroups; ++g) acc[g] = tile_mfma(tbuf, bh[g], bl[g]);
-                    track(td, acc, 4 * (t + 1));
                 }
             }
         }
@@ -757,7 +722,7 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
             if (hasp) t = fmaxf(t, lbm);
             Tmin[g] = bad ? -__builtin_inff() : t;                     // every row survives: the exhaustive evaluation takes over
             thr_b[g] = (Tmin[g] - Eb[g]) * (1.0f - 0x1p-15f);          // for MFMA rows, on keys or values
-            const float thr_p = Tmin[g] * (1.0f - 0x1p-13f);           // for the pairs' upper-bound keys
+            const float thr_p = Tmin[g] * (1.0f - 0x1p-12f);           // for the pairs' upper-bound keys (cut twice: see pair_update)
             const bool live = tc[g].live && nz[g];                 // an all-zero residual projects to 0 everywhere: index -1
             const bool vague = bad || !(thr_b[g] > 0.0f);           // zero pads and everything else would qualify
             const bool unclear_b = vague || !(tb[g].k2 < thr_b[g]) || (has0 && !(td[g].k2 < thr_b[g]));
@@ -1019,6 +984,64 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
         });
         STAMP(10)
 
+        // ---- (8b) the pairs of the tile-channels that go on, for the NEXT step (see `pair_update`): pair 0's P, G and E first
+        float4 pv0[kGroups][4], gv0[kGroups][4];
+        float E0[kGroups];
+        bool on0[kGroups], upd0[kGroups];
+        unsigned info0[kGroups];
+#pragma unroll
+        for (int g = 0; g < kGroups; ++g) {
+            on0[g] = unit[g] >= 0 && tc[g].live && !ended[g] && tc[g].npairs > 0 && tc[g].fresh != 0;
+            upd0[g] = on0[g] && tc[g].coeff != 0.0;
+            info0[g] = tc[g].packed(0);
+            const long long pi = (long long)(g * 16 + slot) * kMaxPairs;
+            const float4* pp = reinterpret_cast<const float4*>(my_p + pi * 64 + 4 * h);
+            const float4* gp = reinterpret_cast<const float4*>(gram + (upd0[g] ? (long long)tc[g].sel_g * a.gram_stride + (int)(info0[g] & 511u) * 64 : 0) + 4 * h);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { pv0[g][t] = pp[4 * t]; gv0[g][t] = gp[4 * t]; }
+            E0[g] = my_e[pi];
+        }
+#pragma unroll
+        for (int g = 0; g < kGroups; ++g) { tp[g] = TopKeys(); lbmax[g] = -3.0e38f; oddp[g] = false; }
+        static_for<kGroups>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            if (__ballot(on0[g])) { COUNT(17, 1) COUNT(18, __popcll(__ballot(on0[g] && h == 0))) }
+            if (on0[g]) pair_update(gc, std::true_type{}, 0, upd0[g], info0[g], pv0[g], gv0[g], E0[g]);
+        });
+#pragma unroll 1
+        for (int p = 1;; ++p) {                                     // further pairs: both groups' loads of a round issued together
+            bool on[kGroups];
+            bool any = false;
+#pragma unroll
+            for (int g = 0; g < kGroups; ++g) {
+                on[g] = unit[g] >= 0 && tc[g].live && !ended[g] && p < tc[g].npairs && p != tc[g].fresh;
+                any = any || (unit[g] >= 0 && tc[g].live && !ended[g] && p < tc[g].npairs);
+            }
+            if (!__ballot(any)) break;
+            unsigned info[kGroups];
+            float4 pv[kGroups][4], gv[kGroups][4];
+            float E[kGroups];
+            bool upd[kGroups];
+#pragma unroll
+            for (int g = 0; g < kGroups; ++g) {
+                const long long pi = (long long)(g * 16 + slot) * kMaxPairs + (on[g] ? p : 0);
+                info[g] = p < 4 ? tc[g].packed(p) : (my_meta[2 * pi] & 0xFFFFu);
+                upd[g] = on[g] && tc[g].coeff != 0.0;
+                const float4* pp = reinterpret_cast<const float4*>(my_p + pi * 64 + 4 * h);
+                const float4* gp = reinterpret_cast<const float4*>(gram + (upd[g] ? (long long)tc[g].sel_g * a.gram_stride + (int)(info[g] & 511u) * 64 : 0) + 4 * h);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { pv[g][t] = pp[4 * t]; gv[g][t] = gp[4 * t]; }
+                E[g] = my_e[pi];
+            }
+            static_for<kGroups>([&](auto gc) {
+                constexpr int g = decltype(gc)::value;
+                COUNT(17, 1) COUNT(18, __popcll(__ballot(on[g] && h == 0)))
+                if (on[g]) pair_update(gc, std::true_type{}, p, upd[g], info[g], pv[g], gv[g], E[g]);
+            });
+        }
+        STAMP(2)
+
+
         // ---- (9) residual update r -= (q * quant) * row: Vector::Scale then Vector::Subtract, two roundings.  Behind it, what
         //      the next step will read from far away is pulled towards the cache by LDS-DMA into a landing zone nobody reads (no
         //      register, no wait): the Gram rows of the pairs, the filter tiles of a new pair.
@@ -1040,14 +1063,6 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
                 for (int i = 0; i < 16; ++i) sq[i] = r[g][i] * r[g][i];
                 const T e2 = chain_sum(sq, h);
                 if (s.live && ended[g] && h == 0) a.out.energy[rec_of(s.t)] = (double)e2;
-            }
-            if (upd && !ended[g] && h < 2) {
-                const int np = s.npairs < 4 ? s.npairs : 4;
-                for (int p = 0; p < np; ++p) {
-                    if (p == s.fresh) continue;
-                    const float* line = gram + (long long)s.sel_g * a.gram_stride + (int)(s.packed(p) & 511u) * 64 + 32 * h;
-                    __builtin_amdgcn_global_load_lds(line, my_touch, 4, 0, 0);
-                }
             }
             unsigned long long pend = __ballot(s.live && !ended[g] && s.fresh >= 0 && s.fresh < 4 && h == 0);
             while (pend) {                                          // a new pair's 16 KiB of filter tiles: 128 lines, two per lane

@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -20,6 +21,7 @@
 #include <vector>
 
 #include "host_bitstream.h"
+#include "mpc_internal.h"
 #include "host_codec.h"
 #include "host_stats.h"
 #include "host_dictionary.h"
@@ -82,9 +84,7 @@ struct DeviceDict {
     float* d_detail32 = nullptr;
     int32_t* d_rows = nullptr;
     int32_t* d_rowoff = nullptr;
-    uint16_t* d_base_f32 = nullptr;   // filter copies, k order 0 (step-synchronous kernels)
-    uint16_t* d_detail_f32 = nullptr;
-    uint16_t* d_base_t1 = nullptr;    // filter copies, k order 1 (persistent kernel)
+    uint16_t* d_base_t1 = nullptr;    // split-bf16 filter copies in MFMA operand order (persistent kernel)
     uint16_t* d_detail_t1 = nullptr;
     uint8_t* d_shadow = nullptr;      // [3][detail_rows]
     float* d_gram = nullptr;          // [3][num_base + detail_rows][num_base * 64]
@@ -100,9 +100,9 @@ struct DeviceDict {
         if (device < 0) return;
         (void)hipSetDevice(device);
         (void)hipDeviceSynchronize();
-        (void)hipFree(d_base); (void)hipFree(d_detail); (void)hipFree(d_rows); (void)hipFree(d_rowoff);
-        (void)hipFree(d_base32); (void)hipFree(d_detail32);
-        (void)hipFree(d_base_f32); (void)hipFree(d_detail_f32); (void)hipFree(d_base_t1); (void)hipFree(d_detail_t1);
+        (void)hipFree(d_base); (void)hipFree(d_rows); (void)hipFree(d_rowoff);      // d_detail / d_detail32: inside d_base / d_base32
+        (void)hipFree(d_base32);
+        (void)hipFree(d_base_t1); (void)hipFree(d_detail_t1);
         (void)hipFree(d_shadow); (void)hipFree(d_gram); (void)hipFree(queues); (void)hipFree(stats);
         (void)hipFree(pair_p); (void)hipFree(pair_meta); (void)hipFree(pair_e);
         if (done[0]) (void)hipEventDestroy(done[0]);
@@ -130,32 +130,35 @@ hipError_t acquire_device_dict(int device, const mpc::Dictionary& dict, std::sha
     std::vector<double> det((3 * det_rows + 1) * mpc::kTileN, 0.0);
     for (int ch = 0; ch < 3; ++ch)
         std::memcpy(det.data() + ch * det_rows * mpc::kTileN, dict.detail[ch].data(), det_rows * mpc::kTileN * sizeof(double));
-    e = upload(&d->d_base, base.data(), base.size());
-    if (e == hipSuccess) e = upload(&d->d_detail, det.data(), det.size());
-    {
-        const std::vector<float> base32(base.begin(), base.end()), det32(det.begin(), det.end());      // round to nearest
-        if (e == hipSuccess) e = upload(&d->d_base32, base32.data(), base32.size());
-        if (e == hipSuccess) e = upload(&d->d_detail32, det32.data(), det32.size());
+    {   // base rows and detail rows in one allocation
+        std::vector<double> all(base);
+        all.insert(all.end(), det.begin(), det.end());
+        e = upload(&d->d_base, all.data(), all.size());
+        d->d_detail = d->d_base + base.size();
+        const std::vector<float> all32(all.begin(), all.end());                                       // round to nearest
+        if (e == hipSuccess) e = upload(&d->d_base32, all32.data(), all32.size());
+        d->d_detail32 = d->d_base32 + base.size();
     }
     if (e == hipSuccess) e = upload(&d->d_rows, dict.block_rows.data(), dict.block_rows.size());
     if (e == hipSuccess) e = upload(&d->d_rowoff, dict.block_row_off.data(), dict.block_row_off.size());
-    // split-bfloat16 filter copies: base rows as 32 tiles of 16 rows, every detail block as 4; both k orders
+    // split-bfloat16 filter copies in MFMA operand order (host_dictionary.h: filter_tiles, k order 1): base rows as 32 tiles of
+    // 16 rows, every detail block as 4
     std::vector<uint8_t> shadow(3 * det_rows, 0);
-    for (int order = 0; order < 2 && e == hipSuccess; ++order) {
-        const std::vector<uint16_t> base32 = mpc::filter_tiles(dict.base.data(), dict.num_base, mpc::kBaseFilterTiles, order);
-        std::vector<uint16_t> det32;
-        det32.reserve(3 * static_cast<size_t>(dict.num_base) * mpc::kBlockFilterTiles * mpc::kFilterTileHalves);
+    if (e == hipSuccess) {
+        const std::vector<uint16_t> base_t = mpc::filter_tiles(dict.base.data(), dict.num_base, mpc::kBaseFilterTiles, 1);
+        std::vector<uint16_t> det_t;
+        det_t.reserve(3 * static_cast<size_t>(dict.num_base) * mpc::kBlockFilterTiles * mpc::kFilterTileHalves);
         for (int ch = 0; ch < 3; ++ch)
             for (int b = 0; b < dict.num_base; ++b) {
                 std::vector<uint8_t> sh;
                 const std::vector<uint16_t> t = mpc::filter_tiles(
                     dict.detail[ch].data() + static_cast<size_t>(dict.block_row_off[b]) * mpc::kTileN, dict.block_rows[b],
-                    mpc::kBlockFilterTiles, order, &sh);
-                det32.insert(det32.end(), t.begin(), t.end());
+                    mpc::kBlockFilterTiles, 1, &sh);
+                det_t.insert(det_t.end(), t.begin(), t.end());
                 std::copy(sh.begin(), sh.end(), shadow.begin() + static_cast<size_t>(ch) * det_rows + static_cast<size_t>(dict.block_row_off[b]));
             }
-        e = upload(order == 0 ? &d->d_base_f32 : &d->d_base_t1, base32.data(), base32.size());
-        if (e == hipSuccess) e = upload(order == 0 ? &d->d_detail_f32 : &d->d_detail_t1, det32.data(), det32.size());
+        e = upload(&d->d_base_t1, base_t.data(), base_t.size());
+        if (e == hipSuccess) e = upload(&d->d_detail_t1, det_t.data(), det_t.size());
     }
     if (e == hipSuccess) e = upload(&d->d_shadow, shadow.data(), shadow.size());
     if (e == hipSuccess) e = hipDeviceGetAttribute(&d->num_cus, hipDeviceAttributeMultiprocessorCount, device);
@@ -204,8 +207,6 @@ struct mpc_context {
     std::recursive_mutex host_calls;  // the host-buffer entry points share the staging buffers below
     int32_t* d_rows = nullptr;
     int32_t* d_rowoff = nullptr;
-    uint16_t* d_base_f32 = nullptr;   // filter copies (mp_device.h)
-    uint16_t* d_detail_f32 = nullptr;
     int* d_flag = nullptr;            // decode: set when a record indexes outside its dictionary
     // grow-only device staging for the host-buffer entry points (mpc_encode_tiles / mpc_encode_image): allocating and
     // freeing five buffers per call cost several times the encode itself
@@ -294,8 +295,6 @@ mpc::DictDevice dict_device(const mpc_context* c) {
     d.block_rows = c->d_rows;
     d.block0_rows = c->dict.block_rows.empty() ? 0 : c->dict.block_rows[0];
     d.block_row_off = c->d_rowoff;
-    d.base_f32 = c->d_base_f32;
-    d.detail_f32 = c->d_detail_f32;
     return d;
 }
 
@@ -312,7 +311,8 @@ int pipes_for(const mpc_context* c, long long tile_channels) {
     return pipes;
 }
 
-// the step-synchronous kernels run only on request (MPC_PATH=steps, or MPC_FILTER=0 for their exhaustive sweeps)
+// the step-synchronous exhaustive sweeps (the product's cross-check of the persistent kernel) run only on request:
+// MPC_PATH=steps, or MPC_FILTER=0 (the older name)
 bool steps_path() {
     const char* v = std::getenv("MPC_PATH");
     return (v && std::strcmp(v, "steps") == 0) || env_int("MPC_FILTER", 1) == 0;
@@ -384,6 +384,7 @@ mpc_status run_persistent(mpc_context* c, const mpc::FrameInput& in, const mpc::
     mpc::PursuitArgs a{};
     a.base = d.d_base;
     a.base32 = d.d_base32;
+
     a.fast = c->fast ? 1 : 0;
     a.base_tiles = d.d_base_t1;
     for (int ch = 0; ch < 3; ++ch) {
@@ -412,6 +413,7 @@ mpc_status run_persistent(mpc_context* c, const mpc::FrameInput& in, const mpc::
     a.tile_row_begin = in.tile_row_begin;
     a.tile_rows = in.tile_rows;
     a.tiles_x = in.tiles_x;
+    a.rgb_aligned8 = (reinterpret_cast<uintptr_t>(in.rgb) % 8 == 0 && in.row_stride % 8 == 0 && (in.frames <= 1 || in.frame_stride % 8 == 0)) ? 1 : 0;
     a.vec_in = in.vec_in;
     a.vec_channel = in.vec_channel;
     a.queue = d.queues;
@@ -486,8 +488,8 @@ mpc_status run_persistent(mpc_context* c, const mpc::FrameInput& in, const mpc::
 
 mpc_status run_pursuit(mpc_context* c, const mpc::FrameInput& in, const mpc::Outputs& out, const double* d_quant,
                        long long total_tc, void* stream) {
-    // MPC_PATH=steps: the step-synchronous kernels of mp_kernels.hip (with MPC_FILTER=0: their exhaustive double sweeps, the
-    // product's own cross-check); default: the persistent kernel
+    // MPC_PATH=steps / MPC_FILTER=0: the step-synchronous exhaustive double sweeps of mp_kernels.hip (the product's own
+    // cross-check); default: the persistent kernel
     if (!steps_path()) return run_persistent(c, in, out, d_quant, total_tc, stream);
     if (c->fast) return fail(MPC_ERR_ARGUMENT, "the float flavour runs on the persistent kernel only (unset MPC_PATH / MPC_FILTER)");
     mpc_status st = ensure_workspace(c, total_tc);
@@ -521,7 +523,7 @@ mpc_status run_pursuit(mpc_context* c, const mpc::FrameInput& in, const mpc::Out
             c->timing_used = need;
         }
         const int err = mpc::enqueue_pursuit(dict, pipe.ws, in, out, d_quant, c->K, begin, static_cast<int>(n),
-                                             env_int("MPC_FILTER", 1) ? 0 : env_int("MPC_BASE_PARTS", kBaseParts), env_int("MPC_ROW_PARTS", kRowParts),
+                                             env_int("MPC_BASE_PARTS", kBaseParts), env_int("MPC_ROW_PARTS", kRowParts),
                                              env_int("MPC_SWEEP_WAVES", c->max_waves), pipe.stream, events,
                                              env_int("MPC_SIDE", 0) ? pipe.side : nullptr, pipe.fork, pipe.join);
         if (err != 0) return fail(MPC_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(err)));
@@ -538,6 +540,7 @@ extern "C" {
 
 const char* mpc_version(void) { return "mpcodec 0.1 (gfx950)"; }
 const char* mpc_last_error(void) { return g_error; }
+void mpc_set_error_text(const char* text) { std::snprintf(g_error, sizeof g_error, "%s", text ? text : ""); }
 
 mpc_status mpc_context_create(int K, int block_size, double bpp, int device, mpc_context** out) {
     return guarded([&]() -> mpc_status {
@@ -573,8 +576,6 @@ mpc_status mpc_context_create(int K, int block_size, double bpp, int device, mpc
             c->d_detail = c->dd->d_detail;
             c->d_rows = c->dd->d_rows;
             c->d_rowoff = c->dd->d_rowoff;
-            c->d_base_f32 = c->dd->d_base_f32;
-            c->d_detail_f32 = c->dd->d_detail_f32;
             c->base_rows_padded = c->dd->base_rows_padded;
         }
         if (e == hipSuccess) e = upload(&c->d_quant, c->quant.data(), c->quant.size());
@@ -857,7 +858,7 @@ mpc_status mpc_calc_mp_batch(mpc_context* c, int channel, const double* quant_k,
     return MPC_OK;
 }
 
-// live timing of the dominant kernel (mp_filter_wave_kernel; mp_base_kernel with MPC_FILTER=0) with HIP events on the launch stream
+// live timing of the dominant kernel (mp_pursuit_kernel; mp_base_kernel with MPC_PATH=steps) with HIP events on the launch stream
 void mpc_kernel_timing_enable(mpc_context* c, int on) {
     if (!c) return;
     c->timing = on != 0;
@@ -1300,6 +1301,17 @@ mpc_status entropy_buffers(mpc_context::EntropySlot& e, size_t tiles, int K, Ent
 
 enum class EntropyResult { kDone, kNeedsHost, kFailed };
 
+// Wait for an event.  `spin`: poll it (a single frame's latency is a chain of such waits, and a sleeping thread takes tens of
+// microseconds to come back); otherwise let the thread sleep -- in the frame pipeline the table building wants the cores.
+hipError_t wait_event(hipEvent_t ev, bool spin) {
+    if (!spin) return hipEventSynchronize(ev);
+    for (;;) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e != hipErrorNotReady) return e;
+        __builtin_ia32_pause();
+    }
+}
+
 double trace_ms() {
     static const auto origin = std::chrono::steady_clock::now();
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - origin).count();
@@ -1372,8 +1384,8 @@ EntropyResult entropy_tables(const EntropyBuffers& b, int device_block_size, int
 }
 
 EntropyResult entropy_collect(const EntropyBuffers& b, const EntropyPending& pending, hipEvent_t done, uint8_t** blob, size_t* nbytes,
-                              double* stamps = nullptr) {
-    if (hipEventSynchronize(done) != hipSuccess) return EntropyResult::kFailed;
+                              double* stamps = nullptr, bool spin = false) {
+    if (wait_event(done, spin) != hipSuccess) return EntropyResult::kFailed;
     if (stamps) stamps[2] = trace_ms();                         // codes written, bytes on the host
     const int S = b.args.n_streams;
     for (int j = 0; j < S; ++j)                                 // the device wrote exactly the bits the tables promise
@@ -1404,12 +1416,12 @@ EntropyResult entropy_collect(const EntropyBuffers& b, const EntropyPending& pen
 // both steps; `enqueued()` (if any) is called between them: once phase 2 is on the stream, or once it is clear that it will not be
 EntropyResult finish_entropy_on_device(const EntropyBuffers& b, int device_block_size, int width, int height, int K, const double* quant,
                                        hipStream_t s, hipEvent_t done, const std::function<void()>& enqueued, uint8_t** blob,
-                                       size_t* nbytes, double* stamps = nullptr) {
+                                       size_t* nbytes, double* stamps = nullptr, bool spin = false) {
     EntropyPending pending;
     const EntropyResult r = entropy_tables(b, device_block_size, width, height, K, quant, s, done, &pending, stamps);
     if (enqueued) enqueued();
     if (r != EntropyResult::kDone) return r;
-    return entropy_collect(b, pending, done, blob, nbytes, stamps);
+    return entropy_collect(b, pending, done, blob, nbytes, stamps, spin);
 }
 }  // namespace
 
@@ -1475,6 +1487,9 @@ static mpc_status encode_sequence(mpc_context* c, const uint8_t* const* frames, 
     HIP_TRY(ensure_workspace(c, static_cast<long long>(n_tc)) == MPC_OK ? hipSuccess : hipErrorOutOfMemory);
     const double* q = quant ? quant : c->quant.data();
     const bool device_entropy = !host_entropy_forced();
+    // a single frame: nothing to overlap with, so its worker runs on the calling thread (no thread to start and to join) and
+    // polls the device instead of sleeping
+    const bool single = n_frames == 1;
     // ONE ordered device queue.  The pursuit kernel fills every CU for milliseconds, and nothing else gets onto the device
     // while it runs -- not a small kernel, not a copy (short copies are blit kernels) -- so work queued beside it on another
     // stream just waits for a gap at a time nobody controls.  Everything therefore goes to seq_compute in the order it should
@@ -1534,19 +1549,21 @@ static mpc_status encode_sequence(mpc_context* c, const uint8_t* const* frames, 
         hipEvent_t ev_up = c->seq_events[usl][0];
         hipStream_t up_stream = c->seq_up;
         const int device = c->device;
-        uploads[usl] = std::async(std::launch::async, [=]() -> hipError_t {
-            constexpr int kCopiers = 8;
-            const size_t piece = ((img_bytes + kCopiers - 1) / kCopiers + 4095) & ~static_cast<size_t>(4095);
-            std::future<void> parts[kCopiers];
-            for (int k = 1; k < kCopiers; ++k) {
-                const size_t lo = std::min(img_bytes, piece * k), hi = std::min(img_bytes, piece * (k + 1));
-                if (hi > lo) parts[k] = std::async(std::launch::async, [=] { std::memcpy(pinned_rgb + lo, src + lo, hi - lo); });
-            }
-            std::memcpy(pinned_rgb, src, std::min(img_bytes, piece));
-            for (int k = 1; k < kCopiers; ++k)
-                if (parts[k].valid()) parts[k].get();
-            hipError_t e = hipSetDevice(device);
-            if (e == hipSuccess) e = hipMemcpyAsync(d_img, pinned_rgb, img_bytes, hipMemcpyHostToDevice, up_stream);
+        uploads[usl] = std::async(single ? std::launch::deferred : std::launch::async, [=]() -> hipError_t {
+            // In chunks: a chunk goes to the device as soon as it is in pinned memory, so the DMA of the first chunks runs while
+            // the later ones are still being copied (a 16 Mpixel frame: 48 MB staged at memcpy speed, then sent at PCIe speed).
+            const size_t chunk = std::max<size_t>(size_t(1) << 20, (((img_bytes + 31) / 32) + 4095) & ~static_cast<size_t>(4095));
+            const int chunks = static_cast<int>((img_bytes + chunk - 1) / chunk);
+            std::atomic<int> failed{static_cast<int>(hipSuccess)};
+            mpc::parallel_io_jobs(chunks, 8, [&](int k) {
+                const size_t lo = chunk * static_cast<size_t>(k), hi = std::min(img_bytes, lo + chunk);
+                std::memcpy(pinned_rgb + lo, src + lo, hi - lo);
+                hipError_t e = hipSetDevice(device);
+                if (e == hipSuccess) e = hipMemcpyAsync(d_img + lo, pinned_rgb + lo, hi - lo, hipMemcpyHostToDevice, up_stream);
+                if (e != hipSuccess) failed.store(static_cast<int>(e));
+            });
+            hipError_t e = static_cast<hipError_t>(failed.load());
+            if (e == hipSuccess) e = hipSetDevice(device);
             if (e == hipSuccess) e = hipEventRecord(ev_up, up_stream);
             return e;
         });
@@ -1634,7 +1651,7 @@ static mpc_status encode_sequence(mpc_context* c, const uint8_t* const* frames, 
         static const bool trace = env_int("MPC_TRACE", 0) != 0;
         auto now_ms = [] { return trace_ms(); };
         const double t_enq = now_ms();
-        slot.result = std::async(std::launch::async, [=]() -> std::pair<uint8_t*, size_t> {
+        slot.result = std::async(single ? std::launch::deferred : std::launch::async, [=]() -> std::pair<uint8_t*, size_t> {
             struct Trace {
                 bool on; int f; double t0, t1 = 0, t2 = 0, t3 = 0, e[3] = {0, 0, 0};
                 ~Trace() {
@@ -1648,13 +1665,13 @@ static mpc_status encode_sequence(mpc_context* c, const uint8_t* const* frames, 
                 void operator()() { if (!done) p->set_value(); done = true; }
                 ~Tell() { (*this)(); }
             } tell{told};
-            if (hipSetDevice(device) != hipSuccess || hipEventSynchronize(ev_comp) != hipSuccess) return {nullptr, 0};
+            if (hipSetDevice(device) != hipSuccess || wait_event(ev_comp, single) != hipSuccess) return {nullptr, 0};
             tr.t1 = now_ms();
             if (device_entropy) {
                 uint8_t* blob = nullptr;
                 size_t n = 0;
                 const EntropyResult r = finish_entropy_on_device(eb, bs, width, height, K, q, phase2_beside ? down : pursuit_stream, ev_down,
-                                                                 [&] { tell(); }, &blob, &n, tr.e);
+                                                                 [&] { tell(); }, &blob, &n, tr.e, single);
                 tr.t2 = tr.t3 = now_ms();
                 if (r == EntropyResult::kDone) return {blob, n};
                 if (r == EntropyResult::kFailed) return {nullptr, 0};

@@ -260,6 +260,16 @@ mpc_status mpc_encode_image_device(mpc_context* ctx, const uint8_t* d_rgb, int w
 mpc_status mpc_encode_images_device(mpc_context* ctx, const uint8_t* const* d_rgb_frames, int n_frames, int width, int height,
                                     const double* quant, uint8_t** bytes, size_t* nbytes);
 
+/* compressed::encodeImage for a sequence of equally sized frames on SEVERAL GPUs of one node from one process (what a
+ * Compression.cpp-style caller gets with MPC_DEVICES=0,1,...: dropin/compressionlib_dropin.cpp).  ctxs[0 .. n_devices): one context
+ * per lane, each created on the device the lane shall use (two lanes may name the same device, not the same context), same K.
+ * Every frame's tile rows are striped over the lanes (contiguous stripes, remainder to the first lanes); a step takes
+ * n_devices frames, frame f of a step is owned by lane f, which pulls the other lanes' stripes of it (hipMemcpyPeerAsync), puts
+ * them into the reference's tile order and produces the container.  bytes[i] / nbytes[i]: frame i's container (mpc_free),
+ * byte-identical to mpc_encode_image.  n_devices == 1 is mpc_encode_images. */
+mpc_status mpc_encode_images_multi(mpc_context* const* ctxs, int n_devices, const uint8_t* const* rgb_frames, int n_frames,
+                                   int width, int height, const double* quant, uint8_t** bytes, size_t* nbytes);
+
 /* Multi-GPU path, between the stripe exchange and the stream assembly: the records of tile rows [tile_row_begin, tile_row_end)
  * of a frame, in the order mpc_encode_tiles_device writes a stripe (t = tx*rows + ty_local), copied to their places in the whole
  * frame's records (t = tx*tiles_y + ty: the reference's visiting order, CompressedImage.cpp:535-537).  Asynchronous on `stream`. */

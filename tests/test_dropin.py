@@ -97,6 +97,18 @@ def test_compression_cpp_call_sequence_emits_the_oracles_bytes(tmp_path, oracle,
 
 
 @pytest.mark.gpu
+def test_compression_cpp_caller_on_two_lanes_emits_the_oracles_bytes(tmp_path, oracle):
+    """MPC_DEVICES=0,0: the drop-in's encodeImage stripes the frame over two lanes (mpc_encode_images_multi, both on the one
+    device of this box); the Compression.cpp-shaped caller still emits the oracle's bytes."""
+    W, H, K = 200, 136, 32
+    rgb = oracle.synth_frame(W, H, 4242)
+    want = bytes(oracle.OracleContext(K, 8, 3.5).encode_image(rgb))
+    out = tmp_path / "two_lanes.mn"
+    _run("c", W, H, 4242, "3.5", out, {"MPC_DEVICES": "0,0"})
+    assert out.read_bytes() == want
+
+
+@pytest.mark.gpu
 def test_round_trip_psnr_and_patch_records(tmp_path, oracle):
     W, H, K = 160, 96, 32
     rgb = oracle.synth_frame(W, H, 99)

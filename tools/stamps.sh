@@ -6,5 +6,5 @@
 set -e
 cd "$(dirname "$0")/../imageexperiments_amd/csrc"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -fPIC -pthread -DMPC_STAMPS \
-    -shared -o ../lib/libmpcodec_stamps.so host_dictionary.cpp host_bitstream.cpp host_codec.cpp host_stats.cpp mp_kernels.hip mp_pursuit.hip mp_streams.hip mp_entropy.hip mpcodec_capi.cpp
+    -shared -o ../lib/libmpcodec_stamps.so host_dictionary.cpp host_bitstream.cpp host_codec.cpp host_stats.cpp mp_kernels.hip mp_pursuit.hip mp_streams.hip mp_entropy.hip mpcodec_capi.cpp mpcodec_multi.cpp
 echo ../lib/libmpcodec_stamps.so
