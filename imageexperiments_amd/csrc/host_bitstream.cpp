@@ -662,7 +662,6 @@ bool huffman_decode(BitReader& in, std::vector<uint16_t>& out) {
     }
     const uint8_t* const bytes = in.data();
     const size_t total_bits = in.size_bits();
-    const size_t safe = total_bits >= 64 ? total_bits - 64 : 0;         // an 8-byte load at bit `pos` stays inside while pos <= safe
     // the symbols go to out[o++]; `out` is kept larger than o (grown geometrically, cut to o on the way out)
     size_t o = out.size();
     struct Trim {
@@ -674,56 +673,74 @@ bool huffman_decode(BitReader& in, std::vector<uint16_t>& out) {
         if (out.size() < o + more) out.resize(std::max<size_t>(out.size() + out.size() / 2, o + more + 4096));
     };
     for (;;) {
-        if (total_bits >= 64) {
-            size_t pos = in.position();
-            while (pos <= safe) {
-                room(16);
+        if (total_bits >= 128) {
+            // A 64-bit bit buffer, refilled without branches: its top `cnt` bits are the next bits of the stream (bits below them
+            // may already hold what follows: harmless); consumed so far = 8 * (ptr - bytes) - cnt.  Up to four table look-ups per
+            // refill (at most kLutBits bits each); a code longer than the window is resolved from the same buffer.
+            const size_t pos = in.position();
+            const uint8_t* ptr = bytes + (pos >> 3);
+            const uint8_t* const last = bytes + total_bits / 8 - 8;         // an 8-byte load at `last` still lies inside the data
+            uint64_t buf = 0;
+            unsigned cnt = 0;
+            auto refill = [&] {
                 uint64_t w;
-                std::memcpy(&w, bytes + (pos >> 3), 8);
-                w = __builtin_bswap64(w) << (pos & 7);                      // at least 57 valid bits
-                unsigned used = 0;
+                std::memcpy(&w, ptr, 8);
+                buf |= __builtin_bswap64(w) >> cnt;
+                ptr += (63 - cnt) >> 3;
+                cnt |= 56;
+            };
+            bool careful = ptr > last;
+            if (!careful) {
+                refill();
+                buf <<= (pos & 7);
+                cnt -= static_cast<unsigned>(pos & 7);
+            }
+            while (!careful && ptr <= last) {
+                room(8);
+                refill();                                                   // cnt >= 56
                 uint16_t* dst = out.data() + o;
-                uint16_t* const stop = dst + 14;
-                bool careful = false;
-                while (dst < stop && used + kLutBits <= 57) {
-                    const uint32_t idx = static_cast<uint32_t>((w << used) >> (64 - kLutBits));
-                    const uint64_t e = fast[idx];
-                    if ((e >> 40) != 0) {
-                        dst[0] = static_cast<uint16_t>(e);
-                        dst[1] = static_cast<uint16_t>(e >> 16);
-                        dst += (e >> 40);
-                        used += static_cast<unsigned>((e >> 32) & 0xFFu);
-                        continue;
-                    }
-                    if (lut[idx] != 0) { careful = true; break; }            // the pseudo-EOF
-                    if (used + static_cast<unsigned>(max_length) > 57) break; // a longer code: from a fresh word
-                    int l = kLutBits + 1;
-                    uint32_t acc = 0;
-                    const uint64_t x = w << used;
-                    if (tiled) {
-                        for (; l <= max_length; ++l)
-                            if (counts[l - 1] && (x < end_left[l] || end_left[l] == 0)) break;
-                        if (l <= max_length) {
-                            acc = static_cast<uint32_t>(x >> (64 - l));
-                            if (acc < first_code[l]) l = max_length + 1;         // below every longer code: not a code at all
-                        }
-                    } else {
-                        for (; l <= max_length; ++l) {                           // the reference's test per length, on the word
-                            acc = static_cast<uint32_t>(x >> (64 - l));
-                            if (counts[l - 1] && acc >= first_code[l] && acc - first_code[l] < counts[l - 1]) break;
-                        }
-                    }
-                    if (l > max_length) { careful = true; break; }           // no code: the careful loop fails as the reference does
-                    const uint32_t entry = first_index[l] + (acc - first_code[l]);
-                    if (entry == eof_entry) { careful = true; break; }
-                    *dst++ = table[entry];
-                    used += static_cast<unsigned>(l);
+                int k = 0;
+                for (; k < 4; ++k) {
+                    const uint64_t e = fast[buf >> (64 - kLutBits)];
+                    if ((e >> 40) == 0) break;
+                    dst[0] = static_cast<uint16_t>(e);
+                    dst[1] = static_cast<uint16_t>(e >> 16);
+                    dst += (e >> 40);
+                    const unsigned n = static_cast<unsigned>((e >> 32) & 0xFFu);
+                    buf <<= n;
+                    cnt -= n;
                 }
                 o = static_cast<size_t>(dst - out.data());
-                pos += used;
-                if (careful) break;
+                if (k == 4) continue;
+                // not in the table: the pseudo-EOF (careful loop), or a code longer than the window
+                if (lut[buf >> (64 - kLutBits)] != 0) { careful = true; break; }
+                if (cnt < static_cast<unsigned>(max_length)) {
+                    if (ptr > last) break;
+                    refill();
+                }
+                int l = kLutBits + 1;
+                uint32_t acc = 0;
+                if (tiled) {
+                    for (; l <= max_length; ++l)
+                        if (counts[l - 1] && (buf < end_left[l] || end_left[l] == 0)) break;
+                    if (l <= max_length) {
+                        acc = static_cast<uint32_t>(buf >> (64 - l));
+                        if (acc < first_code[l]) l = max_length + 1;         // below every longer code: not a code at all
+                    }
+                } else {
+                    for (; l <= max_length; ++l) {                           // the reference's test per length, on the buffer
+                        acc = static_cast<uint32_t>(buf >> (64 - l));
+                        if (counts[l - 1] && acc >= first_code[l] && acc - first_code[l] < counts[l - 1]) break;
+                    }
+                }
+                if (l > max_length) { careful = true; break; }               // no code: the careful loop fails as the reference does
+                const uint32_t entry = first_index[l] + (acc - first_code[l]);
+                if (entry == eof_entry) { careful = true; break; }
+                out[o++] = table[entry];
+                buf <<= l;
+                cnt -= static_cast<unsigned>(l);
             }
-            in.set_position(pos);
+            if (ptr >= bytes + (pos >> 3) + 1 || cnt != 0) in.set_position(8 * static_cast<size_t>(ptr - bytes) - cnt);
         }
         // one symbol the careful way (a long code, the pseudo-EOF, the last bytes of the data)
         const size_t left = in.remaining();
@@ -1448,28 +1465,40 @@ bool read_compressed(const uint8_t* bytes, size_t nbytes, Streams& s) {
             }
         }
     }
+    // The codes are self-delimiting, so the bit stream is parsed serially -- but only the entropy codes: run-length expansion
+    // (:660-678) and the DC sums (:690-705) of a stream need nothing from the streams behind it and run on the pool afterwards.
+    std::vector<std::vector<uint16_t>> packed(static_cast<size_t>(6 * K));
+    std::vector<char> is_packed(static_cast<size_t>(6 * K), 0);
+    std::vector<size_t> expect(static_cast<size_t>(6 * K), 0);
     for (int i = 0; i < 6 * K; ++i) {
-        const size_t expect = expect_of[(static_cast<size_t>(i / 2) / K) * static_cast<size_t>(K) + static_cast<size_t>(i / 2) % K];
+        expect[i] = expect_of[(static_cast<size_t>(i / 2) / K) * static_cast<size_t>(K) + static_cast<size_t>(i / 2) % K];
         if (in.get(1) == 1) {
             const size_t packed_len = static_cast<size_t>(in.get(32));
-            std::vector<uint16_t> packed;
-            if (!read_huffman_or_golomb(in, packed_len, packed)) return false;
+            is_packed[i] = 1;
+            if (!read_huffman_or_golomb(in, packed_len, packed[i])) return false;
+        } else {
+            if (!read_huffman_or_golomb(in, expect[i], s.codes[i])) return false;
+        }
+    }
+    std::vector<char> bad(static_cast<size_t>(6 * K), 0);
+    parallel_for(6 * K, [&](int i) {
+        if (is_packed[i]) {
             // run lengths come from the data: refuse to expand beyond what the lengths stream allows for this stream
             size_t expanded = 0;
-            if (!rle_decoded_size(packed.data(), packed.size(), expect, &expanded)) return false;
-            s.codes[i] = rle_decode(packed.data(), packed.size());
-        } else {
-            if (!read_huffman_or_golomb(in, expect, s.codes[i])) return false;
+            if (!rle_decoded_size(packed[i].data(), packed[i].size(), expect[i], &expanded)) { bad[i] = 1; return; }
+            s.codes[i] = rle_decode(packed[i].data(), packed[i].size());
         }
-        if (s.codes[i].size() != expect) return false;
-    }
-    for (int idx : {1, 2 * K + 1, 4 * K + 1}) {                  // :690-705
-        int32_t acc = 0;
-        for (uint16_t& c : s.codes[idx]) {
-            acc += zigzag_decode(c);
-            c = static_cast<uint16_t>(acc);
+        if (s.codes[i].size() != expect[i]) { bad[i] = 1; return; }
+        if (i == 1 || i == 2 * K + 1 || i == 4 * K + 1) {       // :690-705
+            int32_t acc = 0;
+            for (uint16_t& c : s.codes[i]) {
+                acc += zigzag_decode(c);
+                c = static_cast<uint16_t>(acc);
+            }
         }
-    }
+    });
+    for (int i = 0; i < 6 * K; ++i)
+        if (bad[i]) return false;
     return true;
 }
 
@@ -1528,22 +1557,50 @@ Streams assemble_streams(int width, int height, int K, int block_size, const dou
 
 bool disassemble_streams(const Streams& s, uint16_t* counts, uint32_t* choices) {
     const int K = s.K;
-    const size_t n = s.lengths.size();
-    std::vector<size_t> cursor(static_cast<size_t>(3 * K), 0);
-    for (size_t o = 0; o < n; ++o) {
-        const int ch = static_cast<int>(o % 3);
-        const int count = s.lengths[o];
-        if (count > K) return false;
-        counts[o] = s.lengths[o];
-        for (int i = 0; i < count; ++i) {
-            const std::vector<uint16_t>& d = s.codes[2 * K * ch + 2 * i];
-            const std::vector<uint16_t>& c = s.codes[2 * K * ch + 2 * i + 1];
-            size_t& at = cursor[static_cast<size_t>(ch * K + i)];
-            if (at >= d.size() || at >= c.size()) return false;
-            choices[o * K + i] = static_cast<uint32_t>(d[at]) | (static_cast<uint32_t>(c[at]) << 16);
-            ++at;
+    const size_t n = s.lengths.size(), tiles = n / 3;
+    if (n % 3 != 0) return false;
+    for (int i = 0; i < 6 * K; i += 2)
+        if (s.codes[i].size() != s.codes[i + 1].size()) return false;
+    // Blocks of tiles in parallel: where a block starts in each of the 3K stream pairs = tile-channels of the blocks in front of
+    // it with more than `step` atoms (suffix sums of a histogram of the block's counts, then a running sum over the blocks).
+    const size_t block = 4096, blocks = (tiles + block - 1) / block;
+    std::vector<size_t> start((blocks + 1) * static_cast<size_t>(3 * K), 0);
+    std::vector<char> bad(blocks, 0);
+    parallel_for(static_cast<int>(blocks), [&](int b) {
+        std::vector<size_t> hist(static_cast<size_t>(3 * (K + 1)), 0);
+        const size_t lo = block * static_cast<size_t>(b), hi = std::min(tiles, lo + block);
+        for (size_t o = 3 * lo; o < 3 * hi; ++o) {
+            if (s.lengths[o] > K) { bad[b] = 1; return; }
+            ++hist[(o % 3) * static_cast<size_t>(K + 1) + s.lengths[o]];
         }
-    }
+        size_t* mine = start.data() + (static_cast<size_t>(b) + 1) * static_cast<size_t>(3 * K);
+        for (int ch = 0; ch < 3; ++ch) {
+            size_t above = 0;
+            for (int i = K - 1; i >= 0; --i) {
+                above += hist[static_cast<size_t>(ch) * (K + 1) + static_cast<size_t>(i + 1)];
+                mine[ch * K + i] = above;
+            }
+        }
+    });
+    for (size_t b = 0; b < blocks; ++b)
+        if (bad[b]) return false;
+    for (size_t b = 1; b <= blocks; ++b)
+        for (int p = 0; p < 3 * K; ++p) start[b * static_cast<size_t>(3 * K) + p] += start[(b - 1) * static_cast<size_t>(3 * K) + p];
+    for (int p = 0; p < 3 * K; ++p)                                 // every stream must hold what the lengths promise
+        if (start[blocks * static_cast<size_t>(3 * K) + p] > s.codes[2 * p].size()) return false;
+    parallel_for(static_cast<int>(blocks), [&](int b) {
+        std::vector<size_t> cursor(start.begin() + static_cast<size_t>(b) * (3 * K), start.begin() + (static_cast<size_t>(b) + 1) * (3 * K));
+        const size_t lo = block * static_cast<size_t>(b), hi = std::min(tiles, lo + block);
+        for (size_t o = 3 * lo; o < 3 * hi; ++o) {
+            const int ch = static_cast<int>(o % 3);
+            const int count = s.lengths[o];
+            counts[o] = s.lengths[o];
+            for (int i = 0; i < count; ++i) {
+                const size_t at = cursor[static_cast<size_t>(ch * K + i)]++;
+                choices[o * K + i] = static_cast<uint32_t>(s.codes[2 * K * ch + 2 * i][at]) | (static_cast<uint32_t>(s.codes[2 * K * ch + 2 * i + 1][at]) << 16);
+            }
+        }
+    });
     return true;
 }
 

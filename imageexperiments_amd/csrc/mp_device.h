@@ -187,6 +187,9 @@ struct StreamArgs {
 };
 size_t stream_workspace_words(long long tiles, int K);
 int launch_stream_assembly(const StreamArgs& a, void* stream);
+// the decoder's way back: counts + the 6K streams (in `symbols`, container order, DC coefficients already summed) -> records
+// [tiles][3][K], dead steps zero.  Uses a.counts, a.symbols (read), a.block_live and a.sizes (scratch); not a.stream_off / a.dc_tmp
+int launch_stream_gather(const StreamArgs& a, uint32_t* choices, void* stream);
 // records of the tile rows [row_begin, row_begin + rows) in stripe order -> their places in the whole frame's records
 int launch_interleave_stripe(const uint16_t* part_counts, const uint32_t* part_choices, int tiles_x, int tiles_y, int row_begin, int rows,
                              int K, uint16_t* frame_counts, uint32_t* frame_choices, void* stream);

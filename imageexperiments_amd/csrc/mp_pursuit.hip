@@ -173,10 +173,6 @@ struct TopKeys {
     __device__ __forceinline__ void see(unsigned value_bits, unsigned keep_mask, unsigned code)
     {
         const unsigned key = (value_bits & keep_mask) | code;
-        see_key(key);
-    }
-    __device__ __forceinline__ void see_key(unsigned key)
-    {
         k2 = __builtin_amdgcn_fmed3f(k1, k2, __uint_as_float(key));
         const unsigned k1b = __float_as_uint(k1);
         k1 = __uint_as_float(k1b > key ? k1b : key);
@@ -266,6 +262,22 @@ __device__ __forceinline__ void keep_better(T& v, int& i, int& sel, T ov, int oi
     }
 }
 
+// The lane's number, computed where it is asked for.  Lane-derived values (slot, lane row, scratch addresses) that stay live through
+// the whole main loop are what the register allocator spills first -- and a spilled value comes back from scratch memory behind an
+// s_waitcnt vmcnt(0), a full memory round trip in the middle of a phase.  Two VALU instructions per phase are cheaper: every phase
+// of the main loop starts from FRESH_LANE instead of reading loop-long values (the asm is volatile: neither hoisted nor merged).
+__device__ __forceinline__ int lane_id_fresh()
+{
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+#define FRESH_LANE                                                                    \
+    const int lane = lane_id_fresh();                                                 \
+    const int slot = lane & 15, h = lane >> 4;                                        \
+    const int pix0 = 16 * pos_of(h);                                                  \
+    (void)slot; (void)h; (void)pix0;
+
 // In-kernel phase stamps: diagnostic builds only (-DMPC_STAMPS, tools/stamps.sh); the product build has none.
 #ifdef MPC_STAMPS
 #define STAMP(i)                                              \
@@ -329,9 +341,8 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
     }
     __syncthreads();
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int slot = lane & 15, h = lane >> 4;
-    const int pix0 = 16 * pos_of(h);                                // first of this lane's 16 consecutive pixels
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // scalar: so are the wave's scratch pointers.  lane, slot (= lane & 15), lane row h (= lane >> 4) and pix0 (the first of
+                                                                    // the lane's 16 consecutive pixels): FRESH_LANE, phase by phase
     // the wave's channel and everything that depends on it (wave-uniform: scalar registers)
     int ch = ch_first;
     const T* detail = nullptr;
@@ -385,12 +396,12 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
     };
     // record index of tile-channel t of this channel: counts[rec], choices[rec * K + step]
     auto rec_of = [&](int t) { return a.vec_in ? (long long)t : (long long)t * 3 + ch; };
-    auto lds_tile = [&](uint4 (&dst)[4], int t) {
+    auto lds_tile = [&](uint4 (&dst)[4], int t, int lane) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) dst[q] = s_tiles[t * 256 + q * 64 + lane];
     };
     // tile t of DetailBasis[0] of the wave's channel from memory (a wave away from the workgroup's home channel)
-    auto far_tile = [&](uint4 (&dst)[4], int t) {
+    auto far_tile = [&](uint4 (&dst)[4], int t, int lane) {
         const uint4* tiles = reinterpret_cast<const uint4*>(block_tiles) + lane;
 #pragma unroll
         for (int q = 0; q < 4; ++q) dst[q] = tiles[t * 256 + q * 64];
@@ -411,6 +422,7 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
     // same_p: p is the same in every lane (a loop counter): every key's code then sits in a scalar register of its own
     auto pair_update = [&](auto gc, auto same_p, int p, bool upd, unsigned info, float4 (&pv)[4], const float4 (&gv)[4], float E) {
         constexpr int g = decltype(gc)::value;
+        FRESH_LANE
         const long long pi = (long long)(g * 16 + slot) * kMaxPairs + p;
         const int rows = (int)((info >> 9) & 127u);
         if (upd) {
@@ -430,31 +442,26 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
             oddp[g] = oddp[g] || !(fabsf(c32) < kHuge);
         }
         oddp[g] = oddp[g] || !(E < kHuge);
-        // The pair's two largest |P| of this lane first, as keys (the mask clears the sign; the code names tile and value), E added
-        // to those two only (it is the same for all 64 rows), then merged into the slot's keys with the pair's number in the code.
-        // A key's value part is <= |P| and >= |P| (1 - 2^-14); adding E and cutting again loses as much once more: the threshold
-        // on pair keys is lowered by 2^-12 (thresholds below).  Rows 62 and 63 of a block can be pads (blocks have 62 or 63 rows):
-        // lane row h = 3, tile 3, v = 2, 3.  Their P and G are exactly 0; their upper bound must be 0 too (not E), or a pad could
-        // pass for a survivor.
+        // rows 62 and 63 of a block can be pads (blocks have 62 or 63 rows): lane row h = 3, tile 3, v = 2, 3.  Their P and G
+        // are exactly 0; their upper bound must be 0 too (not E), or a pad could pass for a survivor.
         const bool pad2 = h == 3 && rows < 63, pad3 = h == 3 && rows < 64;
         const unsigned keepp = keep_pair_mask;
-        TopKeys lk;
+        float biggest = 0.0f;                                   // of this pair's |P|: its lower bound is biggest - E
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const float vals[4] = {pv[t].x, pv[t].y, pv[t].z, pv[t].w};
 #pragma unroll
-            for (int v = 0; v < 4; ++v) lk.see(__float_as_uint(vals[v]), keepp, (unsigned)((t << 2) | v));
+            for (int v = 0; v < 4; ++v) {
+                const float m = fabsf(vals[v]);
+                float ub = m + E;
+                if (t == 3 && v == 2) ub = pad2 ? 0.0f : ub;
+                if (t == 3 && v == 3) ub = pad3 ? 0.0f : ub;
+                const unsigned code = (unsigned)((p << 4) | (t << 2) | v);
+                tp[g].see(__float_as_uint(ub), keepp, decltype(same_p)::value ? in_sgpr((unsigned)__builtin_amdgcn_readfirstlane((int)code)) : code);
+                biggest = __builtin_amdgcn_fmed3f(biggest, m, __builtin_inff());
+            }
         }
-        const unsigned pcode = decltype(same_p)::value ? in_sgpr((unsigned)__builtin_amdgcn_readfirstlane(p << 4)) : (unsigned)(p << 4);
-        auto bounded = [&](float key) {                              // the key of (|P| + E) with the pair's number in its code
-            const unsigned kb = __float_as_uint(key), code = kb & 15u;
-            float ub = __uint_as_float(kb & kKeepPair) + E;
-            if ((code == 14u && pad2) || (code == 15u && pad3)) ub = 0.0f;
-            return (__float_as_uint(ub) & kKeepPair) | pcode | code;
-        };
-        tp[g].see_key(bounded(lk.k1));
-        tp[g].see_key(bounded(lk.k2));
-        lbmax[g] = __builtin_amdgcn_fmed3f(lbmax[g], __uint_as_float(__float_as_uint(lk.k1) & kKeepPair) - E, __builtin_inff());
+        lbmax[g] = __builtin_amdgcn_fmed3f(lbmax[g], biggest - E, __builtin_inff());
     };
     for (;;) {
         // ---- (1) refill: slots whose tile-channel has ended take the next tile-channels from the queue, kRefillAt or more at
@@ -467,6 +474,7 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
             const unsigned free_slots = (unsigned)(__ballot(!tc[g].live) & 0xFFFFull);      // lane row 0 speaks for its slot
             const int n_free = __popc(free_slots);
             if (!(n_free >= kRefillAt || (unit[g] < 0 && n_free > 0))) return;
+            FRESH_LANE
             int first = 0;
             if (lane == 0) first = (int)atomicAdd(queue, (unsigned)n_free);
             first = __builtin_amdgcn_readfirstlane(first);
@@ -540,6 +548,7 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
         while (next < 3 && (next == 1 ? a.n_tc[1] : a.n_tc[2]) == 0) ++next;
         if (next >= 3) break;
         int was_on = 0;
+        FRESH_LANE
         if (lane == 0) {
             __hip_atomic_fetch_add(&s_on[next], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             was_on = __hip_atomic_fetch_add(&s_on[ch], -1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -560,7 +569,7 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
         if (!any_unit) break;
         // does this workgroup's LDS hold DetailBasis[0] of this wave's channel?  (it cannot change while the wave has live slots)
         const bool home = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&s_home, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) == ch;
-        static_for<kGroups>([&](auto gc) { n_steps += (unsigned)__popcll(__ballot(unit[decltype(gc)::value] >= 0 && tc[decltype(gc)::value].live && h == 0)); });
+        static_for<kGroups>([&](auto gc) { n_steps += (unsigned)__popcll(__ballot(unit[decltype(gc)::value] >= 0 && tc[decltype(gc)::value].live) & 0xFFFFull); });
         STAMP(0)
         COUNT(12, 1)
         static_for<kGroups>([&](auto gc) { COUNT(16, __popcll(__ballot(tc[decltype(gc)::value].live && unit[decltype(gc)::value] >= 0))) });
@@ -599,8 +608,9 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
             constexpr int g = decltype(gc)::value;
             if (unit[g] < 0) return;
             const bool mine = tc[g].live && tc[g].fresh >= 0;
-            unsigned long long pend = __ballot(mine && h == 0);
+            unsigned long long pend = __ballot(mine) & 0xFFFFull;       // lane row 0 speaks for its slot
             if (!pend) return;
+            FRESH_LANE
             COUNT(19, __popcll(pend))
             unsigned fresh_info = 0;
             if (mine)
@@ -655,7 +665,8 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
         for (int g = 0; g < kGroups; ++g) any0 = any0 || (unit[g] >= 0 && __ballot(tc[g].live && tc[g].has0) != 0);
         n_mfma += 6 * kGroups * (kBaseFilterTiles + (any0 ? kBlockFilterTiles : 0));
         {
-            uint4 ta[4], tbuf[4];
+            FRESH_LANE
+            uint4 ta[4];
             f32x4 acc[kGroups], prev[kGroups];
             const unsigned keep = keep_row_mask;
             auto track = [&](TopKeys (&trk)[kGroups], const f32x4 (&val)[kGroups], unsigned code0) {
@@ -667,31 +678,34 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
 #pragma unroll
                     for (int v = 0; v < 4; ++v) trk[g].see(__float_as_uint(val[g][v]), keep, code[v]);
             };
-            lds_tile(ta, 0);
-            lds_tile(tbuf, 1);
+            // ONE tile buffer: a tile's six MFMAs have read it by the time the next tile's LDS reads land (they are issued
+            // behind the last MFMA and return while the matrix pipe works and the previous tile's results are tracked); a second
+            // buffer bought nothing but 16 more live registers in the phase with the most of them
+            lds_tile(ta, 0, lane);
 #pragma unroll
             for (int g = 0; g < kGroups; ++g) prev[g] = tile_mfma(ta, bh[g], bl[g]);
 #pragma unroll 1
-            for (int t = 1; t < kBaseFilterTiles - 1; t += 2) {     // tiles t (in tbuf) and t + 1 (in ta): no register copies
-                lds_tile(ta, t + 1);
+            for (int t = 1; t < kBaseFilterTiles - 1; t += 2) {     // results alternate between acc and prev: no register copies
+                lds_tile(ta, t, lane);
 #pragma unroll
-                for (int g = 0; g < kGroups; ++g) acc[g] = tile_mfma(tbuf, bh[g], bl[g]);
+                for (int g = 0; g < kGroups; ++g) acc[g] = tile_mfma(ta, bh[g], bl[g]);
                 track(tb, prev, 4 * (t - 1));
-                lds_tile(tbuf, t + 2);                              // t + 2 <= 32: DetailBasis[0]'s first tile is always resident
+                lds_tile(ta, t + 1, lane);
 #pragma unroll
                 for (int g = 0; g < kGroups; ++g) prev[g] = tile_mfma(ta, bh[g], bl[g]);
                 track(tb, acc, 4 * t);
             }
-            // tiles 0 .. 30 are done or in `prev` (tile 30); tile 31 is in tbuf
+            // tiles 0 .. 30 are done or in `prev` (tile 30)
+            lds_tile(ta, kBaseFilterTiles - 1, lane);
 #pragma unroll
-            for (int g = 0; g < kGroups; ++g) acc[g] = tile_mfma(tbuf, bh[g], bl[g]);
+            for (int g = 0; g < kGroups; ++g) acc[g] = tile_mfma(ta, bh[g], bl[g]);
             track(tb, prev, 4 * (kBaseFilterTiles - 2));
             track(tb, acc, 4 * (kBaseFilterTiles - 1));
             if (any0) {
 #pragma unroll 1
                 for (int t = 0; t < kBlockFilterTiles; ++t) {
-                    if (home) lds_tile(ta, kBaseFilterTiles + t);
-                    else far_tile(ta, t);
+                    if (home) lds_tile(ta, kBaseFilterTiles + t, lane);
+                    else far_tile(ta, t, lane);
 #pragma unroll
                     for (int g = 0; g < kGroups; ++g) acc[g] = tile_mfma(ta, bh[g], bl[g]);
                     track(td, acc, 4 * t);
@@ -712,6 +726,7 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
             constexpr int g = decltype(gc)::value;
             pass2[g] = false; rescan[g] = false; thr_b[g] = 0.0f; Tmin[g] = 0.0f;
             if (unit[g] < 0) return;
+            FRESH_LANE
             const bool has0 = tc[g].has0, hasp = tc[g].npairs > 0;
             const float top_b = __uint_as_float(__float_as_uint(reduce4_max(tb[g].k1)) & kKeepRow);
             const float top_d = __uint_as_float(__float_as_uint(reduce4_max(td[g].k1)) & kKeepRow);
@@ -722,7 +737,7 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
             if (hasp) t = fmaxf(t, lbm);
             Tmin[g] = bad ? -__builtin_inff() : t;                     // every row survives: the exhaustive evaluation takes over
             thr_b[g] = (Tmin[g] - Eb[g]) * (1.0f - 0x1p-15f);          // for MFMA rows, on keys or values
-            const float thr_p = Tmin[g] * (1.0f - 0x1p-12f);           // for the pairs' upper-bound keys (cut twice: see pair_update)
+            const float thr_p = Tmin[g] * (1.0f - 0x1p-13f);           // for the pairs' upper-bound keys
             const bool live = tc[g].live && nz[g];                 // an all-zero residual projects to 0 everywhere: index -1
             const bool vague = bad || !(thr_b[g] > 0.0f);           // zero pads and everything else would qualify
             const bool unclear_b = vague || !(tb[g].k2 < thr_b[g]) || (has0 && !(td[g].k2 < thr_b[g]));
@@ -752,12 +767,13 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
         for (int g = 0; g < kGroups; ++g) any2 = any2 || pass2[g];
         if (any2) {
             static_for<kGroups>([&](auto gc) { COUNT(13, pass2[decltype(gc)::value] ? 1 : 0) });
+            FRESH_LANE
             uint4 cur[4], nxt[4];
-            lds_tile(cur, 0);
+            lds_tile(cur, 0, lane);
             const int last = any0 ? kTilesLds : kBaseFilterTiles;
             auto any_tile = [&](uint4 (&dst)[4], int t) {
-                if (t < kBaseFilterTiles || home) lds_tile(dst, t);
-                else far_tile(dst, t - kBaseFilterTiles);
+                if (t < kBaseFilterTiles || home) lds_tile(dst, t, lane);
+                else far_tile(dst, t - kBaseFilterTiles, lane);
             };
             static_for<kGroups>([&](auto gc) { n_mfma += pass2[decltype(gc)::value] ? 6 * last : 0; });
 #pragma unroll 1
@@ -784,6 +800,7 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
         static_for<kGroups>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
             if (unit[g] < 0 || !__ballot(rescan[g])) return;
+            FRESH_LANE
             for (int p = 0; __ballot(rescan[g] && p < tc[g].npairs) != 0; ++p) {
                 if (!(rescan[g] && p < tc[g].npairs)) continue;
                 const long long pi = (long long)(g * 16 + slot) * kMaxPairs + p;
@@ -810,13 +827,15 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
         int best_idx[kGroups], best_sel[kGroups];
         int c0[kGroups], c1[kGroups], c2[kGroups], total[kGroups];
         bool exhaustive[kGroups];
+        const int lane7 = lane_id_fresh();                             // this phase's lane values (its lambdas use them)
+        const int slot7 = lane7 & 15, h7 = lane7 >> 4, pix7 = 16 * pos_of(h7);
 #pragma unroll
         for (int g = 0; g < kGroups; ++g) {
             best_val[g] = 0; best_idx[g] = -1; best_sel[g] = 0;
-            c0[g] = __shfl(sv[g].count, slot);
-            c1[g] = __shfl(sv[g].count, slot + 16);
-            c2[g] = __shfl(sv[g].count, slot + 32);
-            total[g] = c0[g] + c1[g] + c2[g] + __shfl(sv[g].count, slot + 48);
+            c0[g] = __shfl(sv[g].count, slot7);
+            c1[g] = __shfl(sv[g].count, slot7 + 16);
+            c2[g] = __shfl(sv[g].count, slot7 + 32);
+            total[g] = c0[g] + c1[g] + c2[g] + __shfl(sv[g].count, slot7 + 48);
             exhaustive[g] = reduce4_add(sv[g].overflow ? 1u : 0u) != 0u;
         }
         // what a code means for this lane's tile-channel: the row's address, its dictionary index and its Gram row
@@ -827,7 +846,7 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
             else if (seg == 1) { ptr = detail + (long long)row * N; idx = tc[g].off0 + row; sel = a.num_base + row; }
             else {
                 const int p = (code >> 11) & 31;
-                const long long pi = (long long)(g * 16 + slot) * kMaxPairs + p;
+                const long long pi = (long long)(g * 16 + slot7) * kMaxPairs + p;
                 const unsigned meta = my_meta[2 * pi];
                 const int drow = s_rowoff[meta & 511u] + row;
                 ptr = detail + (long long)drow * N;
@@ -845,14 +864,14 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
                 if (on[g]) resolve(gc, code[g], ptr[g], idx[g], sel[g]);
             });
 #pragma unroll
-            for (int g = 0; g < kGroups; ++g) load16(x[g], ptr[g] + pix0);
+            for (int g = 0; g < kGroups; ++g) load16(x[g], ptr[g] + pix7);
 #pragma unroll
             for (int g = 0; g < kGroups; ++g)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) x[g][i] = x[g][i] * r[g][i];          // the reference's l * r, rounded to double
             T p[kGroups];
 #pragma unroll
-            for (int g = 0; g < kGroups; ++g) p[g] = chain_sum(x[g], h);
+            for (int g = 0; g < kGroups; ++g) p[g] = chain_sum(x[g], h7);
 #pragma unroll
             for (int g = 0; g < kGroups; ++g)
                 if (on[g]) keep_better(best_val[g], best_idx[g], best_sel[g], p[g], idx[g], sel[g]);
@@ -867,7 +886,7 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
                 any = any || on[g];
                 const int owner = k < c0[g] ? 0 : (k < c0[g] + c1[g] ? 1 : (k < c0[g] + c1[g] + c2[g] ? 2 : 3));
                 const int local = k - (owner == 0 ? 0 : (owner == 1 ? c0[g] : (owner == 2 ? c0[g] + c1[g] : c0[g] + c1[g] + c2[g])));
-                code[g] = __shfl(sv[g].at(local & 3), slot + 16 * owner);
+                code[g] = __shfl(sv[g].at(local & 3), slot7 + 16 * owner);
             }
             if (!__ballot(any)) break;
             COUNT(14, 1)
@@ -901,7 +920,7 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
                         else {
                             const int p = (n - a.num_base - 64) >> 6, row = (n - a.num_base - 64) & 63;
                             code[g] = (2 << 16) | (p << 11) | row;
-                            if (on[g]) on[g] = row < (int)((my_meta[2 * ((long long)(g * 16 + slot) * kMaxPairs + p)] >> 9) & 127u);
+                            if (on[g]) on[g] = row < (int)((my_meta[2 * ((long long)(g * 16 + slot7) * kMaxPairs + p)] >> 9) & 127u);
                         }
                         any = any || on[g];
                     });
@@ -917,6 +936,7 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
         T xrow[kGroups][16];
 #pragma unroll
         for (int g = 0; g < kGroups; ++g) {
+            FRESH_LANE
             const int sg = (unit[g] >= 0 && tc[g].live && best_idx[g] >= 0) ? best_sel[g] : 0;      // Gram row -> the row itself
             load16(xrow[g], (sg < a.num_base ? base_rows + (long long)sg * N : detail + (long long)(sg - a.num_base) * N) + pix0);
         }
@@ -926,6 +946,7 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
             constexpr int g = decltype(gc)::value;
             ended[g] = false;
             if (unit[g] < 0) return;
+            FRESH_LANE
             TileChannel& s = tc[g];
             s.coeff = 0.0;
             s.fresh = -1;
@@ -991,6 +1012,7 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
         unsigned info0[kGroups];
 #pragma unroll
         for (int g = 0; g < kGroups; ++g) {
+            FRESH_LANE
             on0[g] = unit[g] >= 0 && tc[g].live && !ended[g] && tc[g].npairs > 0 && tc[g].fresh != 0;
             upd0[g] = on0[g] && tc[g].coeff != 0.0;
             info0[g] = tc[g].packed(0);
@@ -1005,7 +1027,7 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
         for (int g = 0; g < kGroups; ++g) { tp[g] = TopKeys(); lbmax[g] = -3.0e38f; oddp[g] = false; }
         static_for<kGroups>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
-            if (__ballot(on0[g])) { COUNT(17, 1) COUNT(18, __popcll(__ballot(on0[g] && h == 0))) }
+            if (__ballot(on0[g])) { COUNT(17, 1) COUNT(18, __popcll(__ballot(on0[g]) & 0xFFFFull)) }
             if (on0[g]) pair_update(gc, std::true_type{}, 0, upd0[g], info0[g], pv0[g], gv0[g], E0[g]);
         });
 #pragma unroll 1
@@ -1024,6 +1046,7 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
             bool upd[kGroups];
 #pragma unroll
             for (int g = 0; g < kGroups; ++g) {
+                FRESH_LANE
                 const long long pi = (long long)(g * 16 + slot) * kMaxPairs + (on[g] ? p : 0);
                 info[g] = p < 4 ? tc[g].packed(p) : (my_meta[2 * pi] & 0xFFFFu);
                 upd[g] = on[g] && tc[g].coeff != 0.0;
@@ -1035,7 +1058,7 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
             }
             static_for<kGroups>([&](auto gc) {
                 constexpr int g = decltype(gc)::value;
-                COUNT(17, 1) COUNT(18, __popcll(__ballot(on[g] && h == 0)))
+                COUNT(17, 1) COUNT(18, __popcll(__ballot(on[g]) & 0xFFFFull))
                 if (on[g]) pair_update(gc, std::true_type{}, p, upd[g], info[g], pv[g], gv[g], E[g]);
             });
         }
@@ -1048,6 +1071,7 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
         static_for<kGroups>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
             if (unit[g] < 0) return;
+            FRESH_LANE
             TileChannel& s = tc[g];
             const bool upd = s.live && s.coeff != 0.0;
             if (upd) {
@@ -1079,6 +1103,7 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
         });
         STAMP(11)
     }
+    FRESH_LANE
     if (lane == 0 && a.stats) {
         atomicAdd(a.stats + 0, (unsigned long long)n_mfma);
         atomicAdd(a.stats + 1, (unsigned long long)n_steps);

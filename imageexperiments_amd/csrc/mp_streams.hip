@@ -140,6 +140,61 @@ __global__ __launch_bounds__(kBlockTiles) void mp_stream_scatter_kernel(const St
     }
 }
 
+// The inverse of the scatter, for the decoder (CompressedImage.cpp:680-705 read the streams back into per-tile records): the same
+// positions -- block offset + rank inside the block -- but the symbols are READ from the 6K streams (`symbols`, laid out as the
+// scatter writes them; the step-0 coefficients already summed up by the host) and every tile's records written whole, dead steps
+// as zeros.
+__global__ __launch_bounds__(kBlockTiles) void mp_stream_gather_kernel(const StreamArgs a, uint32_t* __restrict__ choices)
+{
+    __shared__ unsigned wave_live[kWavesPerBlock][kMaxDeviceK];
+    __shared__ unsigned long long off[6 * kMaxDeviceK + 1];
+    stream_layout(a, off);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long t = (long long)blockIdx.x * kBlockTiles + threadIdx.x;
+    const bool in = t < a.tiles;
+    const unsigned long long below = (1ULL << lane) - 1ULL;
+    for (int ch = 0; ch < 3; ++ch) {
+        const int c = in ? (int)a.counts[t * 3 + ch] : 0;
+        uint32_t rec[kMaxDeviceK];
+        __syncthreads();                                          // wave_live of the previous channel is no longer read
+#pragma unroll
+        for (int i = 0; i < kMaxDeviceK; ++i)
+            if (i < a.K) {
+                const unsigned long long live = __ballot(c > i);
+                if (lane == 0) wave_live[wave][i] = (unsigned)__popcll(live);
+            }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < kMaxDeviceK; ++i) {
+            rec[i] = 0u;
+            if (i < a.K) {
+                const unsigned long long live = __ballot(c > i);
+                if (!live) continue;
+                unsigned before = 0;
+                for (int w = 0; w < wave; ++w) before += wave_live[w][i];
+                if (c > i) {
+                    const unsigned long long pos = (unsigned long long)a.block_live[((long long)blockIdx.x * 3 + ch) * a.K + i] + before +
+                                                   (unsigned)__popcll(live & below);
+                    const unsigned long long od = off[2 * (ch * a.K + i)], oc = off[2 * (ch * a.K + i) + 1];
+                    rec[i] = (uint32_t)a.symbols[od + pos] | ((uint32_t)a.symbols[oc + pos] << 16);
+                }
+            }
+        }
+        if (in) {
+            uint32_t* dst = choices + (t * 3 + ch) * a.K;
+            if ((a.K & 3) == 0) {
+#pragma unroll
+                for (int v = 0; v < kMaxDeviceK / 4; ++v)
+                    if (4 * v < a.K) reinterpret_cast<uint4*>(dst)[v] = make_uint4(rec[4 * v], rec[4 * v + 1], rec[4 * v + 2], rec[4 * v + 3]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < kMaxDeviceK; ++i)
+                    if (i < a.K) dst[i] = rec[i];
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void mp_stream_dc_kernel(const StreamArgs a)
 {
     for (int ch = 0; ch < 3; ++ch) {
@@ -182,6 +237,17 @@ int launch_interleave_stripe(const uint16_t* part_counts, const uint32_t* part_c
     const unsigned blocks = (unsigned)((n_words + 255) / 256 < 4096 ? (n_words + 255) / 256 : 4096);
     hipLaunchKernelGGL(mp_interleave_stripe_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream_), part_counts, part_choices,
                        tiles_x, tiles_y, row_begin, rows, K, frame_counts, frame_choices);
+    return (int)hipGetLastError();
+}
+
+int launch_stream_gather(const StreamArgs& a, uint32_t* choices, void* stream_)
+{
+    hipStream_t s = static_cast<hipStream_t>(stream_);
+    const int blocks = (int)((a.tiles + kBlockTiles - 1) / kBlockTiles);
+    if (blocks < 1 || a.K < 1 || a.K > kMaxDeviceK) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(mp_stream_count_kernel, dim3((unsigned)blocks), dim3(kBlockTiles), 0, s, a);
+    hipLaunchKernelGGL(mp_stream_scan_kernel, dim3((unsigned)(3 * a.K)), dim3(64), 0, s, a, blocks);
+    hipLaunchKernelGGL(mp_stream_gather_kernel, dim3((unsigned)blocks), dim3(kBlockTiles), 0, s, a, choices);
     return (int)hipGetLastError();
 }
 

@@ -2044,43 +2044,74 @@ mpc_status mpc_decode_image(const mpc_context* cc, const uint8_t* bytes, size_t 
     if (!mpc::read_compressed(bytes, nbytes, s)) return fail(MPC_ERR_BITSTREAM, "Invalid input data");
     std::lock_guard<std::recursive_mutex> one_host_call(c->host_calls);     // concurrent decodes share the staging buffers
     if (s.block_size != c->block_size) return fail(MPC_ERR_ARGUMENT, "stream block size %d, context block size %d", s.block_size, c->block_size);
-    // records via the context's pinned host buffer and device staging area (grow-only, shared with the encoder)
+    // The streams -- not the records -- cross PCIe (21 MB instead of 97 for a 16 Mpixel K = 32 frame) through the context's pinned
+    // host buffer and device staging area (grow-only, shared with the encoder); the records are rebuilt on the device
+    // (mp_stream_gather_kernel: the stream assembly's positions, read the other way).
     HIP_TRY(hipSetDevice(c->device));
     const size_t n_tc = s.lengths.size();
+    const size_t tiles = n_tc / 3;
+    if (n_tc != 3 * tiles || s.codes.size() != static_cast<size_t>(6 * s.K)) return fail(MPC_ERR_BITSTREAM, "Invalid bitstream");
     auto up = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
-    const size_t counts_bytes = up(sizeof(uint16_t) * n_tc), choices_bytes = up(sizeof(uint32_t) * n_tc * s.K);
+    std::vector<size_t> stream_at(static_cast<size_t>(6 * s.K) + 1, 0);
+    for (int i = 0; i < 6 * s.K; ++i) {
+        if ((i & 1) && s.codes[i].size() != s.codes[i - 1].size()) return fail(MPC_ERR_BITSTREAM, "Invalid bitstream");
+        stream_at[i + 1] = stream_at[i] + s.codes[i].size();
+    }
+    const size_t n_symbols = stream_at[6 * s.K];
+    for (size_t o = 0; o < n_tc; ++o)
+        if (s.lengths[o] > s.K) return fail(MPC_ERR_BITSTREAM, "Invalid bitstream");
+    const size_t counts_bytes = up(sizeof(uint16_t) * n_tc), symbols_bytes = up(sizeof(uint16_t) * (n_symbols ? n_symbols : 1));
     const size_t quant_bytes = up(sizeof(double) * 3 * s.K);
-    const size_t records_bytes = counts_bytes + choices_bytes + quant_bytes;
+    const size_t upload_bytes = counts_bytes + symbols_bytes + quant_bytes;
+    const size_t choices_bytes = up(sizeof(uint32_t) * n_tc * s.K);
+    const size_t live_bytes = up(sizeof(unsigned) * mpc::stream_workspace_words(static_cast<long long>(tiles), s.K));
+    const size_t sizes_bytes = up(sizeof(unsigned) * 3 * s.K);
     const size_t px = static_cast<size_t>(s.width) * s.height * 3;
-    if (records_bytes > c->host_stage_bytes) {
+    const size_t dev_bytes = upload_bytes + choices_bytes + live_bytes + sizes_bytes + up(px);
+    const size_t pinned_bytes = std::max(upload_bytes, up(px));      // the streams on their way in, later the pixels on their way out
+    if (pinned_bytes > c->host_stage_bytes) {
         if (c->host_stage) (void)hipHostFree(c->host_stage);
         c->host_stage = nullptr;
         c->host_stage_bytes = 0;
-        const hipError_t ea = hipHostMalloc(&c->host_stage, records_bytes, hipHostMallocDefault);
+        const hipError_t ea = hipHostMalloc(&c->host_stage, pinned_bytes, hipHostMallocDefault);
         if (ea != hipSuccess) return fail(MPC_ERR_ALLOC, "pinned staging: %s", hipGetErrorString(ea));
-        c->host_stage_bytes = records_bytes;
+        c->host_stage_bytes = pinned_bytes;
     }
-    if (records_bytes + up(px) > c->stage_bytes) {
+    if (dev_bytes > c->stage_bytes) {
         if (c->stage) (void)hipFree(c->stage);
         c->stage = nullptr;
         c->stage_bytes = 0;
-        const hipError_t ea = hipMalloc(&c->stage, records_bytes + up(px));
+        const hipError_t ea = hipMalloc(&c->stage, dev_bytes);
         if (ea != hipSuccess) return fail(MPC_ERR_ALLOC, "device staging: %s", hipGetErrorString(ea));
-        c->stage_bytes = records_bytes + up(px);
+        c->stage_bytes = dev_bytes;
     }
     char* hbase = static_cast<char*>(c->host_stage);
     uint16_t* counts = reinterpret_cast<uint16_t*>(hbase);
-    uint32_t* choices = reinterpret_cast<uint32_t*>(hbase + counts_bytes);
-    double* q = reinterpret_cast<double*>(hbase + counts_bytes + choices_bytes);
-    if (!mpc::disassemble_streams(s, counts, choices)) return fail(MPC_ERR_BITSTREAM, "Invalid bitstream");
+    uint16_t* symbols = reinterpret_cast<uint16_t*>(hbase + counts_bytes);
+    double* q = reinterpret_cast<double*>(hbase + counts_bytes + symbols_bytes);
+    mpc::parallel_jobs(6 * s.K + 1, [&](int job) {
+        if (job == 0) std::memcpy(counts, s.lengths.data(), sizeof(uint16_t) * n_tc);
+        else if (!s.codes[job - 1].empty())
+            std::memcpy(symbols + stream_at[job - 1], s.codes[job - 1].data(), sizeof(uint16_t) * s.codes[job - 1].size());
+    });
     for (int ch = 0; ch < 3; ++ch)
         for (int i = 0; i < s.K; ++i) q[ch * s.K + i] = static_cast<double>(s.quant[ch][i]);
     char* dbase = static_cast<char*>(c->stage);
     uint16_t* d_counts = reinterpret_cast<uint16_t*>(dbase);
-    uint32_t* d_choices = reinterpret_cast<uint32_t*>(dbase + counts_bytes);
-    double* d_q = reinterpret_cast<double*>(dbase + counts_bytes + choices_bytes);
-    uint8_t* d_rgb = reinterpret_cast<uint8_t*>(dbase + records_bytes);
-    HIP_TRY(hipMemcpy(dbase, hbase, records_bytes, hipMemcpyHostToDevice));
+    uint16_t* d_symbols = reinterpret_cast<uint16_t*>(dbase + counts_bytes);
+    double* d_q = reinterpret_cast<double*>(dbase + counts_bytes + symbols_bytes);
+    uint32_t* d_choices = reinterpret_cast<uint32_t*>(dbase + upload_bytes);
+    uint8_t* d_rgb = reinterpret_cast<uint8_t*>(dbase + upload_bytes + choices_bytes + live_bytes + sizes_bytes);
+    HIP_TRY(hipMemcpyAsync(dbase, hbase, upload_bytes, hipMemcpyHostToDevice, nullptr));
+    mpc::StreamArgs sa{};
+    sa.counts = d_counts;
+    sa.tiles = static_cast<long long>(tiles);
+    sa.K = s.K;
+    sa.block_live = reinterpret_cast<unsigned*>(dbase + upload_bytes + choices_bytes);
+    sa.sizes = reinterpret_cast<unsigned*>(dbase + upload_bytes + choices_bytes + live_bytes);
+    sa.symbols = d_symbols;
+    const int ge = mpc::launch_stream_gather(sa, d_choices, nullptr);
+    if (ge != 0) return fail(MPC_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(ge)));
     const mpc_status st = decode_tiles_on_device(c, d_counts, d_choices, d_q, s.K, s.width, s.height, d_rgb, nullptr);
     if (st != MPC_OK) return st;
     HIP_TRY(hipDeviceSynchronize());
@@ -2089,8 +2120,18 @@ mpc_status mpc_decode_image(const mpc_context* cc, const uint8_t* bytes, size_t 
     if (flag) return fail(MPC_ERR_BITSTREAM, "Invalid bitstream");
     uint8_t* out = static_cast<uint8_t*>(std::malloc(px ? px : 1));
     if (!out) return fail(MPC_ERR_ALLOC, "out of memory");
-    const hipError_t e = hipMemcpy(out, d_rgb, px, hipMemcpyDeviceToHost);
+    // through pinned memory (a copy into fresh pageable pages is staged by the runtime on one thread), then a few threads fault
+    // the caller's pages in and copy
+    const hipError_t e = hipMemcpy(c->host_stage, d_rgb, px, hipMemcpyDeviceToHost);
     if (e != hipSuccess) { std::free(out); return fail(MPC_ERR_HIP, "HIP failure: %s", hipGetErrorString(e)); }
+    {
+        const uint8_t* src = static_cast<const uint8_t*>(c->host_stage);
+        const size_t piece = ((px + 15) / 16 + 4095) & ~static_cast<size_t>(4095);
+        mpc::parallel_jobs(piece ? static_cast<int>((px + piece - 1) / piece) : 0, [&](int k) {
+            const size_t lo = piece * static_cast<size_t>(k), hi = std::min(px, lo + piece);
+            std::memcpy(out + lo, src + lo, hi - lo);
+        });
+    }
     *rgb = out;
     *width = s.width;
     *height = s.height;
