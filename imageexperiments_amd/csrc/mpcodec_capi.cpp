@@ -1574,14 +1574,21 @@ static mpc_status encode_sequence(mpc_context* c, const uint8_t* const* frames, 
         Pending& slot = pending[sl];
         collect(slot);                    // frame f - slots is done with this slot: its download and its entropy stage have finished
         if (st != MPC_OK) break;
-        const int back = assembly_beside ? 3 : 2;
+        // how far the pursuits may run ahead of the small kernels behind them: pursuit(f) waits for the stream assembly + phase 1
+        // of frame f - lag_assembly and for the phase 2 of frame f - back.  These chains only get CUs where a pursuit leaves some;
+        // measured (tools/ab_env_bench.sh, 4928x3264): lags 2 / 3 -> 4 660 Mpix/s, 3 / 3 -> 4 610 - 4 690, 3 / 4 -> 4 000 - 4 300,
+        // 4 / 5 -> 4 090 - 4 680: more slack lets the chains of several frames pile up in front of one pursuit's end.
+        static const int lag_assembly = std::min(4, std::max(2, env_int("MPC_LAG_ASSEMBLY", 2)));
+        static const int lag_phase2 = std::min(5, std::max(lag_assembly, env_int("MPC_LAG_PHASE2", 3)));
+        const int back = assembly_beside ? lag_phase2 : 2;
         if (f >= back && phase2_enqueued[(f - back) % static_cast<int>(slots)].valid()) {
             // frame f - back's phase 2 is on its slot's stream by now: this frame's pursuit starts behind it (the event is the one
             // its worker recorded behind the container's copy; on the host route it is an old one and the wait is empty)
             phase2_enqueued[(f - back) % static_cast<int>(slots)].get();
             if (phase2_beside) MPC_SEQ_TRY(hipStreamWaitEvent(pursuit_stream, c->seq_events[(f - back) % static_cast<int>(slots)][2], 0));
         }
-        if (assembly_beside && f >= 2) MPC_SEQ_TRY(hipStreamWaitEvent(pursuit_stream, c->seq_events[(f - 2) % static_cast<int>(slots)][1], 0));
+        if (assembly_beside && f >= lag_assembly)
+            MPC_SEQ_TRY(hipStreamWaitEvent(pursuit_stream, c->seq_events[(f - lag_assembly) % static_cast<int>(slots)][1], 0));
         char* dbase = static_cast<char*>(c->stage) + static_cast<size_t>(sl) * dev_slot;
         char* hbase = static_cast<char*>(c->host_stage) + static_cast<size_t>(sl) * host_slot;
         const uint8_t* d_rgb = frames[f];

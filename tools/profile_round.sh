@@ -32,6 +32,7 @@ echo "pipeline stats done"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_VALU_MFMA_BUSY_CYCLES \
   --output-format csv -d $O/${tag}_pmc_sq -- python3 $R/tools/quick_bench.py raise 2 > $O/${tag}_pmc_sq.log 2>&1
 python3 $R/tools/pmc_sq_summary.py $O/${tag}_pmc_sq/*/*counter_collection.csv $P/${tag}_pmc_sq_raise.json
+cp $P/${tag}_pmc_sq_raise.json $R/profiles/${tag}_pmc_sq_raise.json      # bench.py quotes it in roofline.limited_by
 echo "pmc sq done"
 cd $R
 python3 bench.py > $P/${tag}_bench_raise.json 2> $O/${tag}_bench_raise.err
@@ -43,8 +44,19 @@ for q in 2.0 2.5 3.0 3.5 4.0 4.5 5.0 5.5 6.0; do
   python3 bench.py --quality $q --no-cpu --steps 10 --warmup 2 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read())
-print(json.dumps({'quality':$q,'value_Mpix_s':d['value'],'ms_per_step':d['ms_per_step'],'device_stage_Mpix_s':d['device_stage_Mpix_s'],'container_bytes':d['config']['container_bytes'],'bpp':d['config']['bpp'],'mfma_frac':d['roofline']['mfma_frac'],'tile_channel_steps':d['roofline']['tile_channel_steps_per_step']}))" >> $P/${tag}_quality_sweep.jsonl
+print(json.dumps({'quality':$q,'value_Mpix_s':d['value'],'ms_per_step':d['ms_per_step'],'device_stage_Mpix_s':d['device_stage_Mpix_s'],'container_bytes':d['config']['container_bytes'],'bpp':d['config']['bpp'],'mfma_frac':d['roofline']['frac'],'tile_channel_steps':d['roofline']['tile_channel_steps_per_step']}))" >> $P/${tag}_quality_sweep.jsonl
 done
 echo "quality sweep done"
 python3 tools/e2e_timing.py > $P/${tag}_e2e_timing.txt 2>/dev/null
+# the frame pipeline's sensitivity to how the runtime maps its streams onto hardware queues
+: > $P/${tag}_hw_queues.txt
+for nq in 1 2 4 8; do
+  GPU_MAX_HW_QUEUES=$nq python3 bench.py --steps 20 --warmup 5 --no-cpu --no-e2e 2>/dev/null | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+print('GPU_MAX_HW_QUEUES=$nq value', d['value'], 'Mpix/s ms_per_step', d['ms_per_step'], 'bytes_match_golden', d['bytes_match_golden'])" >> $P/${tag}_hw_queues.txt
+done
+# one frame at a time: latency of a single mpc_encode_image(_device) call, with the library's own trace
+for w in raise 1080p; do python3 tools/single_frame_trace.py $w 2>&1 | grep -E "single frame|trace" | sed "s/^/$w: /" ; done > $P/${tag}_single_frame.txt
+echo "queues + single frame done"
 cut -c1-600 $P/${tag}_bench_raise.json
