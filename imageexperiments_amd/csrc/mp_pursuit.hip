@@ -40,7 +40,11 @@ constexpr int kTilesLds = kBaseFilterTiles + kBlockFilterTiles;     // 36
 constexpr double W_R = 0.299, W_G = 0.587, W_B = 0.114;            // ImageHelper/inc/misc.h:7-11
 constexpr double U_SCALE = 0.436 / (1.0 - 0.114);
 constexpr double V_SCALE = 0.615 / (1.0 - 0.299);
-constexpr float kSlack = 0x1p-13f;               // E = kSlack |r~| + kAbs bounds the split-bf16 MFMA error (mp_kernels.hip)
+#ifndef MPC_SLACK
+#define MPC_SLACK 0x1p-13f
+#endif
+constexpr float kSlack = MPC_SLACK;              // E = kSlack |r~| + kAbs bounds the split-bf16 MFMA error (derivation: DESIGN.md 3);
+                                                 // a larger value stays valid (more survivors, same results): -DMPC_SLACK=... measures that
 constexpr float kAbs = 0x1p-100f;
 constexpr float kHuge = 1.0e30f;                 // beyond this the f32 side may overflow: the tile-channel is evaluated exhaustively
 #ifndef MPC_REFILL_AT
