@@ -216,6 +216,7 @@ struct mpc_context {
     size_t host_stage_bytes = 0;
     // mpc_encode_images: upload / compute / download streams and per-slot events (upload done, pursuit done, download done)
     hipStream_t seq_up = nullptr, seq_compute = nullptr;
+    bool seq_prioritised = false;                    // the side streams outrank the pursuits' (encode_sequence)
     static constexpr int kSeqSlots = 6;              // frames in flight in mpc_encode_images (a frame's container is ready about
                                                      // three pursuits after its own started)
     int pipes_cap = 0;                               // > 0: at most this many concurrent sub-batches per call
@@ -1476,9 +1477,17 @@ static mpc_status encode_sequence(mpc_context* c, const uint8_t* const* frames, 
         c->stage_bytes = alloc_slots * dev_slot;
     }
     if (!c->seq_up) {
+        // The side streams at the highest priority, the pursuits' at the lowest: CUs a pursuit gives up at its end go to the
+        // waiting chains of small kernels before the next pursuit's workgroups (MPC_SIDE_PRIORITY=0: all equal).  Measured at
+        // 4928x3264 (tools/ab_env_bench.sh): 4 740 against 4 660 Mpix/s, with two side streams for all slots (below).
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        const bool prio = env_int("MPC_SIDE_PRIORITY", 1) != 0 && least != greatest;
+        c->seq_prioritised = prio;
         HIP_TRY(hipStreamCreateWithFlags(&c->seq_up, hipStreamNonBlocking));
-        HIP_TRY(hipStreamCreateWithFlags(&c->seq_compute, hipStreamNonBlocking));
-        for (auto& s : c->seq_down) HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        HIP_TRY(prio ? hipStreamCreateWithPriority(&c->seq_compute, hipStreamNonBlocking, least) : hipStreamCreateWithFlags(&c->seq_compute, hipStreamNonBlocking));
+        for (auto& s : c->seq_down)
+            HIP_TRY(prio ? hipStreamCreateWithPriority(&s, hipStreamNonBlocking, greatest) : hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
         for (hipEvent_t& e : c->seq_pursuit_done) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         // blocking events: a thread waiting for the device sleeps instead of spinning (the entropy stage wants the cores)
         for (auto& slot : c->seq_events)
@@ -1624,11 +1633,12 @@ static mpc_status encode_sequence(mpc_context* c, const uint8_t* const* frames, 
         // of hardware queues, and a slot stream that lands on the pursuit stream's queue lines its kernels up behind the next
         // pursuit -- with three streams in all nothing has to share.  `side_a`: stream assembly + phase 1 (assembly_beside);
         // `down`: phase 2, the container's copy, the host route's copies.
-        // Measured: per-slot streams are 4 % faster on 16 Mpixel frames (4 440 against 4 270 Mpix/s) and bimodal on 2 Mpixel
-        // frames, where the chains are as long as the pursuit's tail (2 960 or 2 260 Mpix/s from run to run; shared: 2 780
-        // every time) -- so small frames share, large ones do not, unless the variable says otherwise.
+        // Measured in round 2 (all streams at one priority): per-slot streams are 4 % faster on 16 Mpixel frames (4 440 against
+        // 4 270 Mpix/s) and bimodal on 2 Mpixel frames, where the chains are as long as the pursuit's tail (2 960 or 2 260 Mpix/s
+        // from run to run; shared: 2 780 every time) -- so small frames share.  With the side streams prioritised (round 3) two
+        // shared ones are the faster choice for large frames too (4 740 against 4 690 Mpix/s with one per slot).
         static const int shared_env = env_int("MPC_SHARED_SIDE_STREAMS", -1);
-        const bool shared_sides = shared_env >= 0 ? shared_env != 0 : tiles < 100000;
+        const bool shared_sides = shared_env >= 0 ? shared_env != 0 : (c->seq_prioritised || tiles < 100000);
         hipStream_t side_a = shared_sides ? c->seq_down[0] : c->seq_down[sl];
         hipStream_t down = shared_sides ? c->seq_down[1] : c->seq_down[sl];
         hipStream_t behind = assembly_beside ? side_a : pursuit_stream;

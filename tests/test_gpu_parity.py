@@ -590,3 +590,37 @@ def test_device_resident_frames_to_containers(gpu, oracle):
             assert bytes(blobs[f]) == bytes(octx.encode_image(frames[f])), (w, h, K, f)
         assert bytes(ctx.encode_image_device(d[0].data_ptr(), w, h)) == bytes(blobs[0])
         ctx.close()
+
+
+def test_container_job_survives_other_calls_on_its_context(gpu, oracle):
+    """A container job owns its buffers: between `begin` and `collect` the context may encode other frames (other geometry: the
+    frame pipeline re-carves and clears ITS entropy slots), decode, and run a second job -- every container still equals the
+    oracle's (the job used to share the pipeline's slot buffers)."""
+    import torch
+    import imageexperiments_amd as ia
+    K = 16
+    ctx = ia.create_compression_context(K, 8, 3.5, device=0)
+    octx = oracle.OracleContext(K, 8, 3.5)
+    W, H = 136, 104
+    rgb = oracle.synth_frame(W, H, 77)
+    tiles = ((W + 7) // 8) * ((H + 7) // 8)
+    d_rgb = torch.from_numpy(rgb).cuda()
+    d_counts = torch.zeros((tiles, 3), dtype=torch.int16, device="cuda")
+    d_choices = torch.zeros((tiles, 3, K), dtype=torch.int32, device="cuda")
+    ctx.encode_tiles_device(d_rgb.data_ptr(), W, H, 3 * W, 0, (H + 7) // 8, d_counts.data_ptr(), d_choices.data_ptr())
+    torch.cuda.synchronize()
+    want = bytes(octx.encode_image(rgb))
+    other = oracle.synth_frame(200, 72, 5)                                   # another geometry through the same context
+    want_other = bytes(octx.encode_image(other))
+    ctx.container_job_begin(0, d_counts.data_ptr(), d_choices.data_ptr(), W, H)
+    assert bytes(ctx.encode_image(other)) == want_other                    # between begin and tables
+    ctx.container_job_begin(1, d_counts.data_ptr(), d_choices.data_ptr(), W, H)     # a second job on the same records
+    ctx.container_job_tables(0)
+    blobs = ctx.encode_images([other, other, other])                        # between tables and collect: the pipeline's slots
+    assert [bytes(b) for b in blobs] == [want_other] * 3
+    assert [bytes(b) for b in ctx.encode_images([rgb, rgb])] == [want] * 2  # ... and the job's own geometry
+    assert (ia.api.decode_image(want_other, ctx) == oracle.decode_image(want_other)).all()
+    ctx.container_job_tables(1)
+    assert bytes(ctx.container_job_collect(0)) == want
+    assert bytes(ctx.container_job_collect(1)) == want
+    assert bytes(ctx.records_to_container_device(d_counts.data_ptr(), d_choices.data_ptr(), W, H)) == want
