@@ -660,6 +660,36 @@ bool huffman_decode(BitReader& in, std::vector<uint16_t>& out) {
         if (end > (1ULL << l)) { tiled = false; break; }
         end_left[l] = end << (64 - l);                                           // end == 2^l wraps to 0: treated below
     }
+    // ... and, for such tables, a second level behind the fast table: the window's entries that are prefixes of longer codes point
+    // to a sub-table indexed by the next w bits (w = the longest code with that prefix - kLutBits), one look-up more instead of a
+    // walk over the lengths.  (symbol | length << 16; length 0 = no code, 0xFF = the pseudo-EOF: both go to the careful loop.)
+    std::vector<uint32_t> sub;
+    if (tiled && max_length > kLutBits && max_length <= 26) {
+        std::vector<uint8_t> wbits(lut.size(), 0);
+        for (int l = kLutBits + 1; l <= max_length; ++l)
+            for (uint32_t k = 0; k < counts[l - 1]; ++k) {
+                const uint32_t prefix = (first_code[l] + k) >> (l - kLutBits);
+                wbits[prefix] = std::max<uint8_t>(wbits[prefix], static_cast<uint8_t>(l - kLutBits));
+            }
+        std::vector<uint32_t> off(lut.size(), 0);
+        size_t total_sub = 0;
+        for (size_t pfx = 0; pfx < lut.size() && total_sub <= (1u << 16); ++pfx)
+            if (wbits[pfx]) { off[pfx] = static_cast<uint32_t>(total_sub); total_sub += size_t(1) << wbits[pfx]; }
+        if (total_sub <= (1u << 16)) {
+            sub.assign(total_sub, 0);
+            for (int l = kLutBits + 1; l <= max_length; ++l)
+                for (uint32_t k = 0; k < counts[l - 1]; ++k) {
+                    const uint32_t v = first_code[l] + k, x = static_cast<uint32_t>(l - kLutBits), prefix = v >> x, w = wbits[prefix];
+                    const uint32_t entry = first_index[l] + k;
+                    const uint32_t val = entry == eof_entry ? 0x00FF0000u : (static_cast<uint32_t>(table[entry]) | (static_cast<uint32_t>(l) << 16));
+                    const uint32_t base = (v & ((1u << x) - 1u)) << (w - x);
+                    for (uint32_t r = 0; r < (1u << (w - x)); ++r) sub[off[prefix] + base + r] = val;
+                }
+            for (size_t pfx = 0; pfx < lut.size(); ++pfx)
+                if (wbits[pfx] && fast[pfx] == 0 && lut[pfx] == 0)
+                    fast[pfx] = static_cast<uint64_t>(off[pfx]) | (static_cast<uint64_t>(wbits[pfx]) << 32) | (3ULL << 40);
+        }
+    }
     const uint8_t* const bytes = in.data();
     const size_t total_bits = in.size_bits();
     // the symbols go to out[o++]; `out` is kept larger than o (grown geometrically, cut to o on the way out)
@@ -700,9 +730,10 @@ bool huffman_decode(BitReader& in, std::vector<uint16_t>& out) {
                 refill();                                                   // cnt >= 56
                 uint16_t* dst = out.data() + o;
                 int k = 0;
+                uint64_t e = 0;
                 for (; k < 4; ++k) {
-                    const uint64_t e = fast[buf >> (64 - kLutBits)];
-                    if ((e >> 40) == 0) break;
+                    e = fast[buf >> (64 - kLutBits)];
+                    if (((e >> 40) - 1) > 1) break;                          // neither one nor two symbols here
                     dst[0] = static_cast<uint16_t>(e);
                     dst[1] = static_cast<uint16_t>(e >> 16);
                     dst += (e >> 40);
@@ -712,6 +743,20 @@ bool huffman_decode(BitReader& in, std::vector<uint16_t>& out) {
                 }
                 o = static_cast<size_t>(dst - out.data());
                 if (k == 4) continue;
+                if ((e >> 40) == 3) {                                       // a longer code, through its prefix's sub-table
+                    const unsigned w = static_cast<unsigned>((e >> 32) & 0xFFu);
+                    if (cnt < static_cast<unsigned>(kLutBits) + w) {
+                        if (ptr > last) break;
+                        refill();
+                    }
+                    const uint32_t e2 = sub[static_cast<uint32_t>(e) + static_cast<uint32_t>((buf << kLutBits) >> (64 - w))];
+                    const unsigned len = e2 >> 16;
+                    if (len == 0 || len == 0xFFu) { careful = true; break; }
+                    out[o++] = static_cast<uint16_t>(e2);
+                    buf <<= len;
+                    cnt -= len;
+                    continue;
+                }
                 // not in the table: the pseudo-EOF (careful loop), or a code longer than the window
                 if (lut[buf >> (64 - kLutBits)] != 0) { careful = true; break; }
                 if (cnt < static_cast<unsigned>(max_length)) {

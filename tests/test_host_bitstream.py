@@ -107,6 +107,41 @@ def test_huffman_large_and_many_ties(ia, oracle):
         assert (ia.huffman_decode(blob) == data).all()
 
 
+def test_huffman_decode_fast_paths(ia, oracle):
+    """The decoder's fast loop (bit buffer, one- or two-symbol table, second-level tables for codes longer than the window) and
+    its fall-backs: geometric frequencies (code lengths up to the twenties: sub-tables), Fibonacci frequencies (lengths beyond 26:
+    the length-by-length route), large flat alphabets (every code longer than the window), long runs of one symbol (two symbols
+    per look-up), and streams shorter than the fast loop's 16 bytes.  Encoded bytes equal the oracle's, decoding returns the data,
+    and a few flipped bits never crash (an error or other symbols, like the reference)."""
+    rng = np.random.default_rng(5)
+    cases = []
+    for ratio in (0.5, 0.62, 0.7, 0.8):                                   # geometric: P(symbol k) ~ ratio^k
+        p = ratio ** np.arange(40)
+        cases.append(rng.choice(40, size=60000, p=p / p.sum()).astype(np.uint16) * 37)
+    fib = [1, 1]
+    while len(fib) < 32:
+        fib.append(fib[-1] + fib[-2])
+    cases.append(np.repeat(np.arange(32, dtype=np.uint16), np.minimum(fib, 200000)).astype(np.uint16))   # very long codes
+    rng.shuffle(cases[-1])
+    cases.append(rng.integers(0, 5000, 200000).astype(np.uint16))           # flat: 12-13 bit codes only
+    cases.append(rng.integers(0, 60000, 30000).astype(np.uint16))           # nearly all symbols distinct
+    cases.append(np.where(rng.random(300000) < 0.97, 7, rng.integers(0, 300, 300000)).astype(np.uint16))
+    cases.append(np.array([3, 3, 1], np.uint16))
+    cases.append(np.arange(9, dtype=np.uint16))
+    for data in cases:
+        blob = ia.huffman_encode(data)
+        assert blob == _oracle_huffman(oracle, data)
+        assert (ia.huffman_decode(blob) == data).all()
+        raw = bytearray(blob)
+        for _ in range(8):                                                   # corrupt: an error or different symbols, never a crash
+            bad = bytearray(raw)
+            bad[int(rng.integers(0, len(bad)))] ^= 1 << int(rng.integers(0, 8))
+            try:
+                ia.huffman_decode(bytes(bad))
+            except ia.MpcError:
+                pass
+
+
 def test_huffman_corrupt_stream_is_an_error(ia):
     """HuffmanTest.cpp CorruptStreamTest: truncated data -> 'Invalid bitstream' (status, not an exception pointer)."""
     data = np.random.default_rng(3).integers(0, 50, 2000).astype(np.uint16)
