@@ -313,11 +313,11 @@ def main():
         out = ctx.encode_images(seq, views=True)
         host_to_bytes = W * H * len(seq) / (time.perf_counter() - t0) / 1e6
         del out
-        ctx.encode_image(host_frames[0])
+        ctx.encode_image(host_frames[0], view=True)
         singles = []
         for _ in range(5):
             t0 = time.perf_counter()
-            ctx.encode_image(host_frames[0])
+            ctx.encode_image(host_frames[0], view=True)                     # the library's buffer as it is
             singles.append(time.perf_counter() - t0)
         single_ms = sorted(singles)[len(singles) // 2] * 1e3
 

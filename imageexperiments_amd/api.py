@@ -304,12 +304,12 @@ def read_compressed(blob):
 def decode_image(blob, ctx):
     """compressed::decodeImage (CompressedImage.h:75) -> uint8 [H,W,3]; reconstructed on ctx's device (no host path)."""
     L = load_library()
-    buf = np.frombuffer(bytes(blob), np.uint8)
+    buf = np.frombuffer(blob, np.uint8)                      # no copy of the container: bytes, bytearray and arrays alike
     out, W, H = _u8p(), C.c_int(), C.c_int()
     _check(L.mpc_decode_image(ctx.h, buf.ctypes.data_as(_u8p), buf.size, C.byref(out),
                               C.byref(W), C.byref(H)))
-    img = np.ctypeslib.as_array(out, shape=(H.value, W.value, 3)).copy()
-    L.mpc_free(C.cast(out, C.c_void_p))
+    # the pixels stay in the buffer the library returned (the array owns it and frees it with mpc_free): no 48 MB copy per frame
+    img = _take_view(L, out, C.c_size_t(3 * W.value * H.value)).reshape(H.value, W.value, 3)
     return img
 
 
@@ -506,8 +506,9 @@ class CompressionContext:
         _check(self.L.mpc_kernel_counters_read(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
-    def encode_image(self, rgb, quant=None):
-        """compressed::encodeImage (CompressedImage.h:59): device tile encode + host entropy stage -> bytes."""
+    def encode_image(self, rgb, quant=None, view=False):
+        """compressed::encodeImage (CompressedImage.h:59) -> bytes (view=True: a read-only uint8 array on the buffer the library
+        returned, as a C caller holds it: no Python-side copy of the container)."""
         rgb = np.ascontiguousarray(rgb, np.uint8)
         H, W = rgb.shape[:2]
         qp = None
@@ -516,7 +517,7 @@ class CompressionContext:
             qp = quant.ctypes.data_as(_dp)
         out, n = _u8p(), C.c_size_t(0)
         _check(self.L.mpc_encode_image(self.h, rgb.ctypes.data_as(_u8p), W, H, qp, C.byref(out), C.byref(n)))
-        return _take_bytes(self.L, out, n)
+        return (_take_view if view else _take_bytes)(self.L, out, n)
 
     def encode_images(self, frames, quant=None, views=False):
         """encodeImage for a sequence of equally sized frames in host memory, pipelined (mpc_encode_images).  Returns a list of

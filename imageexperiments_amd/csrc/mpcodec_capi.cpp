@@ -2057,8 +2057,11 @@ mpc_status mpc_decode_image(const mpc_context* cc, const uint8_t* bytes, size_t 
     if (!cc || !bytes || !rgb || !width || !height) return fail(MPC_ERR_ARGUMENT, "null argument");
     mpc_context* c = const_cast<mpc_context*>(cc);
     if (c->device < 0) return fail(MPC_ERR_NO_DEVICE, "context was created without a device; there is no CPU fallback");
+    static const bool trace = env_int("MPC_TRACE", 0) != 0;
+    const double t_begin = trace_ms();
     mpc::Streams s;
     if (!mpc::read_compressed(bytes, nbytes, s)) return fail(MPC_ERR_BITSTREAM, "Invalid input data");
+    const double t_parsed = trace_ms();
     std::lock_guard<std::recursive_mutex> one_host_call(c->host_calls);     // concurrent decodes share the staging buffers
     if (s.block_size != c->block_size) return fail(MPC_ERR_ARGUMENT, "stream block size %d, context block size %d", s.block_size, c->block_size);
     // The streams -- not the records -- cross PCIe (21 MB instead of 97 for a 16 Mpixel K = 32 frame) through the context's pinned
@@ -2119,6 +2122,7 @@ mpc_status mpc_decode_image(const mpc_context* cc, const uint8_t* bytes, size_t 
     double* d_q = reinterpret_cast<double*>(dbase + counts_bytes + symbols_bytes);
     uint32_t* d_choices = reinterpret_cast<uint32_t*>(dbase + upload_bytes);
     uint8_t* d_rgb = reinterpret_cast<uint8_t*>(dbase + upload_bytes + choices_bytes + live_bytes + sizes_bytes);
+    const double t_staged = trace_ms();
     HIP_TRY(hipMemcpyAsync(dbase, hbase, upload_bytes, hipMemcpyHostToDevice, nullptr));
     mpc::StreamArgs sa{};
     sa.counts = d_counts;
@@ -2132,6 +2136,7 @@ mpc_status mpc_decode_image(const mpc_context* cc, const uint8_t* bytes, size_t 
     const mpc_status st = decode_tiles_on_device(c, d_counts, d_choices, d_q, s.K, s.width, s.height, d_rgb, nullptr);
     if (st != MPC_OK) return st;
     HIP_TRY(hipDeviceSynchronize());
+    const double t_device = trace_ms();
     int flag = 0;
     HIP_TRY(hipMemcpy(&flag, c->d_flag, sizeof(int), hipMemcpyDeviceToHost));
     if (flag) return fail(MPC_ERR_BITSTREAM, "Invalid bitstream");
@@ -2149,6 +2154,9 @@ mpc_status mpc_decode_image(const mpc_context* cc, const uint8_t* bytes, size_t 
             std::memcpy(out + lo, src + lo, hi - lo);
         });
     }
+    if (trace)
+        std::fprintf(stderr, "[trace] decode: parse %.2f ms | streams staged %.2f | upload + gather + reconstruct %.2f | pixels to the caller %.2f\n",
+                     t_parsed - t_begin, t_staged - t_parsed, t_device - t_staged, trace_ms() - t_device);
     *rgb = out;
     *width = s.width;
     *height = s.height;

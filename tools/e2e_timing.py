@@ -22,7 +22,7 @@ for name, (W, H, K, q) in bench.WORKLOADS.items():
     ctx = ia.create_compression_context(K, 8, q, device=0)
     (counts, choices, en, sw), t_tiles = timed(lambda: ctx.encode_tiles(rgb))
     blob, t_host = timed(lambda: ia.assemble_streams(W, H, K, 8, ctx.quant, counts, choices.view(np.uint32)))
-    blob2, t_image = timed(lambda: ctx.encode_image(rgb))
+    blob2, t_image = timed(lambda: ctx.encode_image(rgb, view=True))      # the library's buffer as it is (no Python copy)
     assert bytes(blob) == bytes(blob2)
     frames = [rgb] * 16
     blobs, t_pipe = timed(lambda: ctx.encode_images(frames, views=True), reps=2)       # the library's buffers as they are

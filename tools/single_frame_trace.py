@@ -25,7 +25,7 @@ def main():
         print(f"single frame {i}: {dt * 1e3:.2f} ms = {W * H / dt / 1e6:.0f} Mpix/s ({len(blob)} bytes)", file=sys.stderr)
     for i in range(3):
         t = time.perf_counter()
-        blob = ctx.encode_image(rgb)
+        blob = ctx.encode_image(rgb, view=True)
         dt = time.perf_counter() - t
         print(f"single frame from host memory {i}: {dt * 1e3:.2f} ms = {W * H / dt / 1e6:.0f} Mpix/s", file=sys.stderr)
 
