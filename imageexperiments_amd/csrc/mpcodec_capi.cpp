@@ -1561,7 +1561,8 @@ static mpc_status encode_sequence(mpc_context* c, const uint8_t* const* frames, 
         uploads[usl] = std::async(single ? std::launch::deferred : std::launch::async, [=]() -> hipError_t {
             // In chunks: a chunk goes to the device as soon as it is in pinned memory, so the DMA of the first chunks runs while
             // the later ones are still being copied (a 16 Mpixel frame: 48 MB staged at memcpy speed, then sent at PCIe speed).
-            const size_t chunk = std::max<size_t>(size_t(1) << 20, (((img_bytes + 31) / 32) + 4095) & ~static_cast<size_t>(4095));
+            static const size_t parts = static_cast<size_t>(std::min(64, std::max(1, env_int("MPC_UPLOAD_CHUNKS", 32))));
+            const size_t chunk = std::max<size_t>(size_t(1) << 20, (((img_bytes + parts - 1) / parts) + 4095) & ~static_cast<size_t>(4095));
             const int chunks = static_cast<int>((img_bytes + chunk - 1) / chunk);
             std::atomic<int> failed{static_cast<int>(hipSuccess)};
             mpc::parallel_io_jobs(chunks, 8, [&](int k) {
