@@ -126,6 +126,11 @@ def _bind_bitstream(L):
     L.mpc_container_job_begin.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int, _dp, vp]
     L.mpc_container_job_tables.argtypes = [vp, C.c_int]
     L.mpc_container_job_collect.argtypes = [vp, C.c_int, C.POINTER(_u8p), C.POINTER(C.c_size_t)]
+    try:
+        L.mpc_container_job_cancel.argtypes = [vp, C.c_int]
+    except AttributeError:
+        if not os.environ.get("MPCODEC_LIB"):
+            raise
     L.mpc_decode_tiles_device.argtypes = [vp, vp, vp, _dp, C.c_int, C.c_int, vp, vp]
     L.mpc_decode_image.argtypes = [vp, _u8p, C.c_size_t, C.POINTER(_u8p), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.mpc_patch_stats_create.argtypes = [vp, C.c_uint, C.POINTER(vp)]
@@ -604,6 +609,10 @@ class CompressionContext:
         out, n = _u8p(), C.c_size_t(0)
         _check(self.L.mpc_container_job_collect(self.h, slot, C.byref(out), C.byref(n)))
         return (_take_view if views else _take_bytes)(self.L, out, n)
+
+    def container_job_cancel(self, slot):
+        """mpc_container_job_cancel: give the slot up whatever step its job is at."""
+        _check(self.L.mpc_container_job_cancel(self.h, slot))
 
     def calc_mp(self, channel, vectors, quant_k=None):
         """matching::CalcMPDynamic (MatchingPursuit.h:22) on the device for vectors[n,64].

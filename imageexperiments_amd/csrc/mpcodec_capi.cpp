@@ -1911,6 +1911,24 @@ mpc_status mpc_container_job_collect(mpc_context* c, int slot, uint8_t** bytes, 
     });
 }
 
+mpc_status mpc_container_job_cancel(mpc_context* c, int slot) {
+    return guarded([&]() -> mpc_status {
+    if (!c || slot < 0 || slot >= mpc_context::kSeqSlots) return fail(MPC_ERR_ARGUMENT, "bad argument");
+    std::lock_guard<std::recursive_mutex> one_host_call(c->host_calls);
+    if (!c->jobs[slot]) return MPC_OK;
+    ContainerJob* j = job_of(c, slot);
+    if (j->stage != 0 && c->device >= 0) {
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipStreamSynchronize(j->stream));          // whatever the job has enqueued has left its buffers
+    }
+    std::free(j->blob);
+    j->blob = nullptr;
+    j->nblob = 0;
+    j->stage = 0;
+    return MPC_OK;
+    });
+}
+
 mpc_status mpc_interleave_stripe_device(mpc_context* c, const uint16_t* d_part_counts, const mpc_basis_choice* d_part_choices, int width,
                                         int height, int tile_row_begin, int tile_row_end, uint16_t* d_frame_counts,
                                         mpc_basis_choice* d_frame_choices, void* stream) {

@@ -26,6 +26,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <future>
 #include <string>
 #include <thread>
@@ -273,12 +274,29 @@ extern "C" mpc_status mpc_encode_images_multi(mpc_context* const* ctxs, int n_de
         (void)hipStreamSynchronize(me.up_stream);
     };
 
+    auto guarded_lane = [&](int r) {                                   // nothing may leave a lane's thread but a flag
+        try {
+            run_lane(r);
+        } catch (const std::exception& e) {
+            if (lanes[static_cast<size_t>(r)].error.empty()) lanes[static_cast<size_t>(r)].error = text("lane %d: %s", r, e.what());
+            failed = true;
+        } catch (...) {
+            failed = true;
+        }
+    };
     if (!failed) {
         std::vector<std::thread> threads;
-        for (int r = 1; r < N; ++r) threads.emplace_back(run_lane, r);
-        run_lane(0);
+        try {
+            for (int r = 1; r < N; ++r) threads.emplace_back(guarded_lane, r);
+        } catch (...) {
+            failed = true;                                              // a lane without a thread: the others give up at their next wait
+        }
+        guarded_lane(0);
         for (auto& t : threads) t.join();
     }
+    if (failed)                                                         // jobs that were begun and never collected: their slots back to idle
+        for (int r = 0; r < N; ++r)
+            for (int slot = 0; slot < 3; ++slot) (void)mpc_container_job_cancel(ctxs[r], slot);
     std::string why;
     for (auto& l : lanes) {
         if (why.empty() && !l.error.empty()) why = l.error;

@@ -295,6 +295,9 @@ mpc_status mpc_container_job_begin(mpc_context* ctx, int slot, const uint16_t* d
                                    int height, const double* quant, void* stream);
 mpc_status mpc_container_job_tables(mpc_context* ctx, int slot);
 mpc_status mpc_container_job_collect(mpc_context* ctx, int slot, uint8_t** bytes, size_t* nbytes);
+/* Gives a slot up whatever step its job is at (a caller that failed elsewhere between `begin` and `collect`): waits for what the
+ * job has enqueued, drops its result, leaves the slot idle.  An idle slot: no-op. */
+mpc_status mpc_container_job_cancel(mpc_context* ctx, int slot);
 
 /* matching::FromCoeffsDynamic (MatchingPursuit.h:25) + img::RGBFromYUV for every tile of a frame on the device:
  * records in the reference's order (tile t = tx*tiles_y + ty, as mpc_encode_tiles returns them for the whole

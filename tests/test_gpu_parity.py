@@ -624,3 +624,14 @@ def test_container_job_survives_other_calls_on_its_context(gpu, oracle):
     assert bytes(ctx.container_job_collect(0)) == want
     assert bytes(ctx.container_job_collect(1)) == want
     assert bytes(ctx.records_to_container_device(d_counts.data_ptr(), d_choices.data_ptr(), W, H)) == want
+    # a job given up half way leaves its slot usable
+    ctx.container_job_begin(2, d_counts.data_ptr(), d_choices.data_ptr(), W, H)
+    with pytest.raises(ia.MpcError):
+        ctx.container_job_begin(2, d_counts.data_ptr(), d_choices.data_ptr(), W, H)        # busy
+    ctx.container_job_cancel(2)
+    ctx.container_job_begin(2, d_counts.data_ptr(), d_choices.data_ptr(), W, H)
+    ctx.container_job_tables(2)
+    ctx.container_job_cancel(2)
+    ctx.container_job_begin(2, d_counts.data_ptr(), d_choices.data_ptr(), W, H)
+    ctx.container_job_tables(2)
+    assert bytes(ctx.container_job_collect(2)) == want

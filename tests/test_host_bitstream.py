@@ -299,6 +299,10 @@ def test_container_jobs_refuse_misuse_without_touching_a_device(ia):
     with pytest.raises(ia.MpcError) as e:
         ctx.container_job_begin(0, 1, 1, 64, 64)
     assert e.value.status == ia.api.MPC_ERR_NO_DEVICE
+    ctx.container_job_cancel(0)                                   # an idle slot: no-op
+    ctx.container_job_cancel(5)
+    with pytest.raises(ia.MpcError):
+        ctx.container_job_cancel(6)
     for call in (lambda: ctx.container_job_tables(0), lambda: ctx.container_job_collect(0), lambda: ctx.container_job_tables(99),
                  lambda: ctx.container_job_collect(-1)):
         with pytest.raises(ia.MpcError) as e:
