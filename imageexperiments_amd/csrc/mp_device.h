@@ -196,13 +196,13 @@ int launch_interleave_stripe(const uint16_t* part_counts, const uint32_t* part_c
 
 // ---- device-side entropy stage (mp_entropy.hip): everything that touches every symbol of the 1 + 6K streams ----
 constexpr int kEntBlock = 4096;         // symbols per scan block
-constexpr int kEntHistSpan = 4;         // scan blocks per histogram block
+constexpr int kEntHistSpan = 4;         // scan blocks per histogram span and range of symbol values (ent_hist_kernel)
 constexpr int kEntMaxStreams = 6 * kMaxDeviceK + 1;
 
 struct EntStream {                      // one per stream; the device fills the first part, the host the second
     unsigned long long raw_off;         // first symbol of the stream in `symbols` (stream 0 = `lengths`: the counts array)
     unsigned n;                         // symbols of the stream as assembled
-    unsigned blk_begin, hblk_begin;     // first scan block / histogram block
+    unsigned blk_begin;                 // first scan block
     unsigned rle_size;                  // symbols runLengthEncode emits (Huffman.cpp:246-279)
     unsigned shorter;                   // 1 = the run-length coded stream is what gets coded (CompressedImage.cpp:450)
     unsigned eff_n;                     // symbols that get coded
@@ -223,7 +223,8 @@ struct EntropyArgs {
     int n_streams;                      // 6K + 1
     uint16_t* packed;                   // run-length coded streams, at the offsets of their sources (capacity of `symbols`)
     EntStream* streams;                 // [n_streams]
-    unsigned* totals;                   // [4]: scan blocks, histogram blocks, triples written, triple overflow flag
+    unsigned* totals;                   // [4]: scan blocks, (unused), triples written, triple overflow flag
+    unsigned* blk_stream;               // per scan block: the stream it belongs to
     unsigned* blk_lead;                 // per scan block: symbols in front of its first run start | run ends there << 31
     unsigned* blk_inner;                // ... run-length symbols emitted for the runs that start inside the block
     unsigned* blk_tail;                 // ... symbols from its last run start to its end

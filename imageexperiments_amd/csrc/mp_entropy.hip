@@ -14,8 +14,8 @@
 //     plan     per stream: the run a block continues (a segmented scan over the blocks), symbols emitted for those in
 //              closed form, output offsets, the reference's decision `packed.size() + 4 < stream.size()`
 //     pack     the run-length coded stream, for the streams where it is shorter
-//     hist     histogram and first position of every symbol of the stream that will be coded (LDS for symbols < 8192)
-//     hist     ... and the number of distinct symbols (a bin's first count)
+//     hist     histogram and first position of every symbol of the stream that will be coded, in LDS (a workgroup per span of
+//              the stream and range of 8192 symbol values), and the number of distinct symbols (a bin's first count)
 //     compact  (symbol, count, first position) of the symbols that occur, per stream, in one list written straight to host memory
 //     mirror   the per-stream records to host memory
 //   host: Huffman tables / Golomb parameter, bit offsets of every stream's payload in the container
@@ -45,18 +45,9 @@ __device__ __forceinline__ const uint16_t* raw_stream(const EntropyArgs& a, int 
     return j == 0 ? a.counts : a.symbols + s.raw_off;
 }
 
-// stream of scan block / histogram block `b`: the last j with begin[j] <= b (begin is non-decreasing)
-template <bool kHist>
-__device__ __forceinline__ int find_stream(const EntropyArgs& a, unsigned b)
-{
-    int lo = 0, hi = a.n_streams - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        const unsigned begin = kHist ? a.streams[mid].hblk_begin : a.streams[mid].blk_begin;
-        if (begin <= b) lo = mid; else hi = mid - 1;
-    }
-    return lo;
-}
+// stream of scan block `b` (the layout kernel's table: a search over the streams' first blocks would be eight dependent loads
+// in front of every workgroup's work)
+__device__ __forceinline__ int find_stream(const EntropyArgs& a, unsigned b) { return (int)a.blk_stream[b]; }
 
 __device__ __forceinline__ unsigned wave_incl_add(unsigned v)
 {
@@ -88,6 +79,37 @@ __device__ __forceinline__ unsigned block_excl_add(unsigned v, unsigned* scratch
     return before + incl - v;
 }
 
+// A block's symbols go through LDS: the threads of the runs and code kernels each own 16 CONSECUTIVE symbols (32 bytes -- a lane
+// stride that makes every 2-byte load of a wave touch 64 separate lines), so the block is fetched by coalesced 4-byte loads
+// and the threads pick their symbols out of LDS.  8 words are stored as 9: with the threads 8 words apart all lanes would
+// share 4 banks.
+constexpr int kStageWords = ((kEntBlock + 4 + 1) / 2 + 7) / 8 * 9;
+
+__device__ __forceinline__ int staged_at(int s) { return s + ((s >> 4) << 1); }      // index in halves, padding included
+
+// symbols [first, first + count) of the stream at `src` -> lds; the staged index of symbol `first` (0 or 1: the loads start at
+// a 4-byte boundary; the word behind the last symbol may reach 2 bytes past it -- inside the buffers, which end 256-aligned)
+__device__ __forceinline__ int stage_symbols(const uint16_t* src, unsigned first, unsigned count, uint32_t* lds)
+{
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(src + first);
+    const int shift = (int)((addr >> 1) & 1);
+    const uint32_t* words = reinterpret_cast<const uint32_t*>(addr - 2 * (uintptr_t)shift);
+    const int n_words = (int)((count + (unsigned)shift + 1u) >> 1);
+    constexpr int kRounds = ((kEntBlock + 4 + 1) / 2 + kThreads - 1) / kThreads;      // all loads in flight before the first store
+    uint32_t got[kRounds];
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) {
+        const int w = threadIdx.x + r * kThreads;
+        got[r] = w < n_words ? words[w] : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) {
+        const int w = threadIdx.x + r * kThreads;
+        if (w < n_words) lds[w + (w >> 3)] = got[r];
+    }
+    return shift;
+}
+
 // symbols runLengthEncode emits at offset c of a chunk, when the symbol there is / is not the last of its maximal run
 __device__ __forceinline__ unsigned rle_emitted(unsigned c, bool run_end)
 {
@@ -113,7 +135,7 @@ __device__ __forceinline__ unsigned rle_emitted_span(unsigned p0, unsigned len, 
 // ---- phase 1 ----
 __global__ __launch_bounds__(kThreads) void ent_layout_kernel(const EntropyArgs a)
 {
-    __shared__ unsigned nblk[kEntMaxStreams], nhblk[kEntMaxStreams];
+    __shared__ unsigned nblk[kEntMaxStreams], nblk_end;
     const int j = threadIdx.x;
     if (j < a.n_streams) {
         const unsigned long long begin = j == 0 ? 0ULL : a.stream_off[j - 1];
@@ -124,21 +146,26 @@ __global__ __launch_bounds__(kThreads) void ent_layout_kernel(const EntropyArgs 
         s.eff_n = n;
         a.streams[j] = s;
         nblk[j] = (n + kEntBlock - 1) / kEntBlock;
-        nhblk[j] = (n + kEntHistSpan * kEntBlock - 1) / (kEntHistSpan * kEntBlock);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        unsigned b = 0, h = 0;
+        unsigned b = 0;
         for (int s = 0; s < a.n_streams; ++s) {
             a.streams[s].blk_begin = b;
-            a.streams[s].hblk_begin = h;
-            b += nblk[s];
-            h += nhblk[s];
+            const unsigned n = nblk[s];
+            nblk[s] = b;                                  // count -> first block
+            b += n;
         }
+        nblk_end = b;
         a.totals[0] = b;
-        a.totals[1] = h;
+        a.totals[1] = 0;
         a.totals[2] = 0;                                  // triples written
         a.totals[3] = 0;                                  // overflow flag
+    }
+    __syncthreads();
+    if (j < a.n_streams) {
+        const unsigned end = j + 1 < a.n_streams ? nblk[j + 1] : nblk_end;
+        for (unsigned b = nblk[j]; b < end; ++b) a.blk_stream[b] = (unsigned)j;
     }
 }
 
@@ -151,7 +178,7 @@ __global__ __launch_bounds__(kThreads) void ent_runs_kernel(const EntropyArgs a)
     __shared__ unsigned inner_sum;
     const unsigned b = blockIdx.x;
     if (b >= a.totals[0]) return;
-    const int j = find_stream<false>(a, b);
+    const int j = find_stream(a, b);
     const EntStream s = a.streams[j];
     const unsigned lb = b - s.blk_begin;
     const unsigned begin = lb * kEntBlock, len = min((unsigned)kEntBlock, s.n - begin);
@@ -178,12 +205,17 @@ __global__ __launch_bounds__(kThreads) void ent_runs_kernel(const EntropyArgs a)
         inner_sum = 0;
     }
     // the thread's symbols with one neighbour on either side
+    __shared__ uint32_t staged[kStageWords];
+    const unsigned first_staged = begin ? begin - 1 : 0u;
+    const int shift = stage_symbols(src, first_staged, min(s.n, begin + len + 1) - first_staged, staged);
+    __syncthreads();
+    const uint16_t* staged16 = reinterpret_cast<const uint16_t*>(staged);
     const unsigned t0 = threadIdx.x * kPer;
     uint16_t v[kPer + 2];
 #pragma unroll
     for (int k = 0; k < kPer + 2; ++k) {
         const long long gi = (long long)begin + t0 + k - 1;
-        v[k] = (gi >= 0 && gi < (long long)s.n && t0 + k <= len + 1) ? src[gi] : (uint16_t)0;
+        v[k] = (gi >= 0 && gi < (long long)s.n && t0 + k <= len + 1) ? staged16[staged_at((int)(gi - first_staged) + shift)] : (uint16_t)0;
     }
     unsigned bnd_mask = 0, end_mask = 0;                  // bit k: position t0 + k starts / ends a maximal run
     int my_last = -1;
@@ -332,37 +364,75 @@ __global__ __launch_bounds__(64) void ent_rle_plan_kernel(const EntropyArgs a)
     }
 }
 
+// Histogram and first positions of the stream that will be coded.  A workgroup counts the symbols of one RANGE of kLdsBins
+// values in one span of its stream, all in LDS: the deltaId streams use most of the 16-bit range (a few thousand distinct symbols
+// each), and counting those with atomics on memory -- two per symbol -- cost more than everything else in this file together.
+// A stream whose largest symbol needs r ranges gets r workgroups per span and spans r times as long, so the bins set up and
+// flushed per symbol stay the same.  The grid's layout (which workgroup does what) follows from the streams' sizes and largest
+// symbols, known only now: every workgroup derives it again (one scan over <= 193 streams).
 __global__ __launch_bounds__(kThreads) void ent_hist_kernel(const EntropyArgs a)
 {
     __shared__ unsigned hist[kLdsBins], first[kLdsBins];
+    __shared__ unsigned wg_begin[kEntMaxStreams + 1];
+    __shared__ unsigned scratch[kThreads / 64];
+    static_assert(kEntMaxStreams <= kThreads, "one thread per stream in the layout scan");
+    unsigned mine = 0;
+    if ((int)threadIdx.x < a.n_streams) {
+        const unsigned n = a.streams[threadIdx.x].eff_n, ranges = a.streams[threadIdx.x].largest / kLdsBins + 1;
+        const unsigned span = kEntHistSpan * kEntBlock * ranges;
+        mine = n ? ((n + span - 1) / span) * ranges : 0u;
+    }
+    unsigned total;
+    const unsigned before = block_excl_add(mine, scratch, &total);
+    if ((int)threadIdx.x < a.n_streams) wg_begin[threadIdx.x] = before;
+    __syncthreads();
     const unsigned hb = blockIdx.x;
-    if (hb >= a.totals[1]) return;
-    const int j = find_stream<true>(a, hb);
+    if (hb >= total) return;
+    int j = 0;
+    {
+        int lo = 0, hi = a.n_streams - 1;                 // the last stream with wg_begin <= hb that has workgroups at all
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (wg_begin[mid] <= hb) lo = mid; else hi = mid - 1;
+        }
+        j = lo;                                           // streams without workgroups share their successor's wg_begin: the
+    }                                                     // search ends on the last of a run, which is the one with workgroups
     const EntStream s = a.streams[j];
-    const unsigned begin = (hb - s.hblk_begin) * (kEntHistSpan * kEntBlock);
+    const unsigned ranges = s.largest / kLdsBins + 1, span = kEntHistSpan * kEntBlock * ranges;
+    const unsigned local = hb - wg_begin[j], range = local % ranges;
+    const unsigned begin = (local / ranges) * span;
     if (begin >= s.eff_n) return;
-    const unsigned end = min(s.eff_n, begin + kEntHistSpan * kEntBlock);
+    const unsigned end = min(s.eff_n, begin + span);
     const uint16_t* src = s.shorter ? a.packed + s.raw_off : raw_stream(a, j, s);
-    const int bins = (int)min((unsigned)kLdsBins, s.largest + 1);       // the runs kernels have found the largest symbol
+    const unsigned lo_sym = range * kLdsBins;
+    const int bins = (int)min((unsigned)kLdsBins, s.largest + 1 - lo_sym);       // the runs kernels have found the largest symbol
     for (int i = threadIdx.x; i < bins; i += kThreads) {
         hist[i] = 0;
         first[i] = kNoPos;
     }
     __syncthreads();
-    unsigned* ghist = a.ghist + (size_t)j * 65536;
-    unsigned* gfirst = a.gfirst + (size_t)j * 65536;
-    unsigned fresh = 0;                                   // bins this thread was the first to count into
-    for (unsigned i = begin + threadIdx.x; i < end; i += kThreads) {
-        const unsigned sym = src[i];
-        if (sym < kLdsBins) {
-            atomicAdd(&hist[sym], 1u);
-            atomicMin(&first[sym], i);
-        } else {
-            fresh += atomicAdd(&ghist[sym], 1u) == 0;
-            atomicMin(&gfirst[sym], i);
+    constexpr int kInFlight = 8;                          // loads per thread before the first is used: two workgroups fit a CU
+    for (unsigned base = begin + threadIdx.x; base < end; base += kInFlight * kThreads) {
+        unsigned sym[kInFlight];
+#pragma unroll
+        for (int u = 0; u < kInFlight; ++u) {
+            const unsigned i = base + u * kThreads;
+            sym[u] = i < end ? (unsigned)src[i] : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int u = 0; u < kInFlight; ++u) {
+            const unsigned i = base + u * kThreads;
+            const unsigned bin = sym[u] - lo_sym;         // below the range: wraps to something huge
+            if (bin < (unsigned)bins) {
+                atomicAdd(&hist[bin], 1u);
+                if (first[bin] > i) atomicMin(&first[bin], i);                   // a bin's first position settles early; later symbols only look
+            }
         }
     }
     __syncthreads();
+    unsigned* ghist = a.ghist + (size_t)j * 65536 + lo_sym;
+    unsigned* gfirst = a.gfirst + (size_t)j * 65536 + lo_sym;
+    unsigned fresh = 0;                                   // bins this thread was the first to count into
     for (int i = threadIdx.x; i < bins; i += kThreads) {
         const unsigned h = hist[i];
         if (h) {
@@ -483,7 +553,7 @@ __global__ __launch_bounds__(kThreads) void ent_code_kernel(const EntropyArgs a)
     __shared__ unsigned scratch[kThreads / 64];
     const unsigned b = blockIdx.x;
     if (b >= a.totals[0]) return;
-    const int j = find_stream<false>(a, b);
+    const int j = find_stream(a, b);
     const EntStream s = a.streams[j];
     const unsigned begin = (b - s.blk_begin) * kEntBlock;
     if (begin >= s.eff_n) {
@@ -498,12 +568,16 @@ __global__ __launch_bounds__(kThreads) void ent_code_kernel(const EntropyArgs a)
     const unsigned gb = bit_width_u32(m), glimit = (1u << (gb + 1)) - m;
     const unsigned* tcode = a.tcode + (size_t)j * 65536;
     const uint8_t* tlen = a.tlen + (size_t)j * 65536;
+    __shared__ uint32_t staged[kStageWords];
+    const int shift = stage_symbols(src, 0, len, staged);
+    __syncthreads();
+    const uint16_t* staged16 = reinterpret_cast<const uint16_t*>(staged);
     unsigned sym[kPer], bits = 0;
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
         sym[k] = 0;
         if (t0 + k < len) {
-            sym[k] = src[t0 + k];
+            sym[k] = staged16[staged_at((int)(t0 + k) + shift)];
             bits += golomb ? golomb_bits(sym[k], m, gb, glimit) : (unsigned)tlen[sym[k]];
         }
     }
@@ -586,7 +660,8 @@ int launch_entropy_phase1(const EntropyArgs& a, unsigned long long capacity_symb
     hipStream_t st = static_cast<hipStream_t>(stream_);
     if (a.n_streams < 1 || a.n_streams > kEntMaxStreams) return (int)hipErrorInvalidValue;
     const unsigned blocks = (unsigned)entropy_max_blocks(capacity_symbols, a.n_streams);
-    const unsigned hblocks = (unsigned)((capacity_symbols + kEntHistSpan * kEntBlock - 1) / (kEntHistSpan * kEntBlock)) + (unsigned)a.n_streams;
+    // a stream of n symbols and r ranges: ceil(n / (span * r)) * r <= n / span + r workgroups, r <= 65536 / kLdsBins
+    const unsigned hblocks = (unsigned)(capacity_symbols / (kEntHistSpan * kEntBlock)) + (unsigned)a.n_streams * (65536 / kLdsBins + 1);
     hipLaunchKernelGGL(ent_layout_kernel, dim3(1), dim3(kThreads), 0, st, a);
     hipLaunchKernelGGL(ent_runs_kernel<false>, dim3(blocks), dim3(kThreads), 0, st, a);
     hipLaunchKernelGGL(ent_rle_plan_kernel, dim3((unsigned)a.n_streams), dim3(64), 0, st, a);

@@ -86,30 +86,34 @@ __device__ __forceinline__ void stream_layout(const StreamArgs& a, unsigned long
 
 __global__ __launch_bounds__(kBlockTiles) void mp_stream_scatter_kernel(const StreamArgs a)
 {
-    __shared__ unsigned wave_live[kWavesPerBlock][kMaxDeviceK];
+    __shared__ unsigned wave_live[kWavesPerBlock][kMaxDeviceK];   // live tiles of the waves in front of this one, per step
+    __shared__ unsigned block_at[3 * kMaxDeviceK];                // the block's first position in each stream
     __shared__ unsigned long long off[6 * kMaxDeviceK + 1];
     stream_layout(a, off);
     if (blockIdx.x == 0)                                          // for the kernels and copies that follow
         for (int s = threadIdx.x; s <= 6 * a.K; s += kBlockTiles) a.stream_off[s] = off[s];
+    if ((int)threadIdx.x < 3 * a.K) block_at[threadIdx.x] = a.block_live[(long long)blockIdx.x * 3 * a.K + threadIdx.x];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long t = (long long)blockIdx.x * kBlockTiles + threadIdx.x;
     const bool in = t < a.tiles;
     const unsigned long long below = (1ULL << lane) - 1ULL;
     for (int ch = 0; ch < 3; ++ch) {
-        const int c = in ? (int)a.counts[t * 3 + ch] : 0;
+        const int c = in ? min((int)a.counts[t * 3 + ch], a.K) : 0;
+        // only the live part of the record is read: a lane asks for the 16-byte pieces that hold its first c steps (most
+        // tile-channels stop after a few steps, and the dead steps are three quarters of the records' bytes)
         uint32_t rec[kMaxDeviceK];
         {
             const uint4* src = reinterpret_cast<const uint4*>(a.choices + ((in ? t : 0) * 3 + ch) * a.K);
 #pragma unroll
             for (int v = 0; v < kMaxDeviceK / 4; ++v) {
                 uint4 x = make_uint4(0, 0, 0, 0);
-                if (4 * v < a.K && (a.K & 3) == 0) x = src[v];
+                if (4 * v < c && (a.K & 3) == 0) x = src[v];
                 rec[4 * v] = x.x; rec[4 * v + 1] = x.y; rec[4 * v + 2] = x.z; rec[4 * v + 3] = x.w;
             }
             if ((a.K & 3) != 0) {                                // K not a multiple of 4: records are not 16-byte aligned
                 const uint32_t* s1 = a.choices + ((in ? t : 0) * 3 + ch) * a.K;
 #pragma unroll
-                for (int i = 0; i < kMaxDeviceK; ++i) rec[i] = i < a.K ? s1[i] : 0u;
+                for (int i = 0; i < kMaxDeviceK; ++i) rec[i] = i < c ? s1[i] : 0u;
             }
         }
         __syncthreads();                                          // wave_live of the previous channel is no longer read
@@ -120,16 +124,23 @@ __global__ __launch_bounds__(kBlockTiles) void mp_stream_scatter_kernel(const St
                 if (lane == 0) wave_live[wave][i] = (unsigned)__popcll(live);
             }
         __syncthreads();
+        if ((int)threadIdx.x < a.K) {                             // counts -> exclusive prefix over the waves, once per step
+            unsigned run = 0;
+#pragma unroll
+            for (int w = 0; w < kWavesPerBlock; ++w) {
+                const unsigned n = wave_live[w][threadIdx.x];
+                wave_live[w][threadIdx.x] = run;
+                run += n;
+            }
+        }
+        __syncthreads();
 #pragma unroll
         for (int i = 0; i < kMaxDeviceK; ++i)
             if (i < a.K) {
                 const unsigned long long live = __ballot(c > i);
                 if (!live) continue;
-                unsigned before = 0;
-                for (int w = 0; w < wave; ++w) before += wave_live[w][i];
                 if (c > i) {
-                    const unsigned long long pos = (unsigned long long)a.block_live[((long long)blockIdx.x * 3 + ch) * a.K + i] + before +
-                                                   (unsigned)__popcll(live & below);
+                    const unsigned long long pos = (unsigned long long)block_at[ch * a.K + i] + wave_live[wave][i] + (unsigned)__popcll(live & below);
                     const unsigned long long od = off[2 * (ch * a.K + i)], oc = off[2 * (ch * a.K + i) + 1];
                     a.symbols[od + pos] = (uint16_t)(rec[i] & 0xFFFFu);
                     // step-0 coefficients go through the difference kernel: parked behind the end of all streams

@@ -217,6 +217,7 @@ struct mpc_context {
     // mpc_encode_images: upload / compute / download streams and per-slot events (upload done, pursuit done, download done)
     hipStream_t seq_up = nullptr, seq_compute = nullptr;
     bool seq_prioritised = false;                    // the side streams outrank the pursuits' (encode_sequence)
+    int seq_workgroups = 0;                          // > 0: the pursuits of a frame sequence leave CUs to the kernels behind them
     static constexpr int kSeqSlots = 6;              // frames in flight in mpc_encode_images (a frame's container is ready about
                                                      // three pursuits after its own started)
     int pipes_cap = 0;                               // > 0: at most this many concurrent sub-batches per call
@@ -376,6 +377,7 @@ mpc_status run_persistent(mpc_context* c, const mpc::FrameInput& in, const mpc::
     // queues run dry (mp_pursuit.hip: channel switch), so a small frame spreads over the channels by itself.
     const int per_wg = mpc::pursuit_units_per_workgroup();
     int workgroups = static_cast<int>(std::min<long long>((n_units + per_wg - 1) / per_wg, d.workgroups));
+    if (c->seq_workgroups > 0) workgroups = std::min(workgroups, c->seq_workgroups);
     const int forced = env_int("MPC_WORKGROUPS", 0);
     if (forced > 0) workgroups = std::min(forced, d.workgroups);
     std::lock_guard<std::mutex> hold(d.launch_lock);
@@ -1233,7 +1235,7 @@ mpc_status entropy_buffers(mpc_context::EntropySlot& e, size_t tiles, int K, Ent
     const size_t tcode_b = up(sizeof(unsigned) * 65536 * S), tlen_b = up(65536 * static_cast<size_t>(S));
     const size_t out_b = up(packed_b + 65536);
     const size_t hist_b = tcode_b;                        // ghist, gfirst: [S][65536] words each
-    const size_t dev_need = streams_b + totals_b + 6 * blk_u32 + blk_u64 + packed_b + tcode_b + tlen_b + out_b + 2 * hist_b;
+    const size_t dev_need = streams_b + totals_b + 7 * blk_u32 + blk_u64 + packed_b + tcode_b + tlen_b + out_b + 2 * hist_b;
     const size_t host_need = streams_b + totals_b + 2 * triples_b + out_b;
     if (dev_need > e.dev_bytes) {
         HIP_TRY(hipDeviceSynchronize());
@@ -1264,6 +1266,7 @@ mpc_status entropy_buffers(mpc_context::EntropySlot& e, size_t tiles, int K, Ent
     a.n_streams = S;
     a.streams = reinterpret_cast<mpc::EntStream*>(d); d += streams_b;
     a.totals = reinterpret_cast<unsigned*>(d); d += totals_b;
+    a.blk_stream = reinterpret_cast<unsigned*>(d); d += blk_u32;
     a.blk_lead = reinterpret_cast<unsigned*>(d); d += blk_u32;
     a.blk_inner = reinterpret_cast<unsigned*>(d); d += blk_u32;
     a.blk_tail = reinterpret_cast<unsigned*>(d); d += blk_u32;
@@ -1499,6 +1502,20 @@ static mpc_status encode_sequence(mpc_context* c, const uint8_t* const* frames, 
     // a single frame: nothing to overlap with, so its worker runs on the calling thread (no thread to start and to join) and
     // polls the device instead of sleeping
     const bool single = n_frames == 1;
+    // A pursuit on every CU leaves the small kernels behind the previous frames' pursuits (stream assembly, entropy phases: ~8 %
+    // of a frame's CU time) nowhere to run but the gap between two pursuits, where they are latency-bound and the chip idles for
+    // ~0.45 ms per 16 Mpixel frame.  With one CU in eight left free they run beside the pursuit instead.  Measured on one box
+    // (tools/ab_env_bench.sh, MPC_SEQ_WORKGROUPS = pursuit workgroups of 256): 4928x3264 K=32  256: 4 780, 240: 4 620, 224: 5 060,
+    // 216: 4 980, 208: 4 870 Mpix/s; 1920x1080 K=8  256: 3 300 - 3 790, 224: 4 150; 7680x4320 K=16  256: 5 570, 224: 5 860 (with
+    // 16 CUs the chains cannot keep up and the pursuits wait for them).
+    struct SeqWorkgroups {
+        mpc_context* c;
+        ~SeqWorkgroups() { c->seq_workgroups = 0; }
+    } seq_workgroups{c};
+    if (!single && c->num_cus >= 16) {
+        static const int env_wg = env_int("MPC_SEQ_WORKGROUPS", -1);
+        c->seq_workgroups = env_wg >= 0 ? env_wg : c->num_cus - c->num_cus / 8;
+    }
     // ONE ordered device queue.  The pursuit kernel fills every CU for milliseconds, and nothing else gets onto the device
     // while it runs -- not a small kernel, not a copy (short copies are blit kernels) -- so work queued beside it on another
     // stream just waits for a gap at a time nobody controls.  Everything therefore goes to seq_compute in the order it should
