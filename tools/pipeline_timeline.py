@@ -11,9 +11,10 @@ pipe = [i for k, i in enumerate(idx[:-1]) if any("mp_stream_count" in rows[j]["K
 a, b = pipe[-5], pipe[-3]
 t0 = int(rows[a]["Start_Timestamp"])
 out = ["# bench.py: two consecutive frames of the timed call in steady state, every kernel the device ran (rocprofv3 --kernel-trace)\n"
-       "# start_ms end_ms duration_ms kernel   -- pursuits back to back on one stream; behind each, on its slot's stream: stream "
-       "assembly + entropy phase 1 (f), later phase 2 + container copy (f); they run in the next pursuits' tails (a kernel's "
-       "start is its dispatch: a long 'duration' of a small kernel is time spent waiting for a free CU)\n"]
+       "# start_ms end_ms duration_ms kernel   -- pursuits back to back on one stream (224 workgroups on 256 CUs); behind each, on the "
+       "side streams: stream assembly + entropy phase 1 (f), later phase 2 + container copy (f), beside the next pursuits on the CUs "
+       "they leave free.  The copyBuffer kernel is the profiler's doing: without rocprofv3 the container's copy is an SDMA copy "
+       "(DESIGN.md 4).  Run bench.py with --no-e2e: the legs behind the timed call would be picked up instead\n"]
 for r in rows[a:b + 1]:
     s, e = (int(r["Start_Timestamp"]) - t0) / 1e6, (int(r["End_Timestamp"]) - t0) / 1e6
     name = r["Kernel_Name"].split("(")[0].replace("mpc::", "").replace("void ", "")

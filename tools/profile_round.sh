@@ -25,7 +25,7 @@ for w in raise 1080p 8k; do
   echo "pmc $w done"
 done
 # the whole pipeline of bench.py's value (pursuit, stream assembly, entropy kernels, the container's copy) in one trace
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_stats_pipeline -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu > $O/${tag}_stats_pipeline.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_stats_pipeline -- python3 $R/bench.py --steps 14 --warmup 4 --no-cpu --no-e2e > $O/${tag}_stats_pipeline.log 2>&1
 cp $O/${tag}_stats_pipeline/*/*kernel_stats.csv $P/${tag}_kernel_stats_pipeline_raise.csv
 python3 $R/tools/pipeline_timeline.py $O/${tag}_stats_pipeline/*/*kernel_trace.csv $P/${tag}_timeline_pipeline_raise.txt
 echo "pipeline stats done"
