@@ -59,6 +59,7 @@ def load_library():
         getattr(L, "mpc_context_" + f).argtypes = [vp]
         getattr(L, "mpc_context_" + f).restype = C.c_int
     L.mpc_context_set_fast.argtypes = [vp, C.c_int]
+    L.mpc_context_set_tile_encode_workgroups.argtypes = [vp, C.c_int]
     L.mpc_context_is_fast.argtypes = [vp]
     L.mpc_context_is_fast.restype = C.c_int
     L.mpc_context_get_quant.argtypes = [vp, _dp]
@@ -438,6 +439,10 @@ class CompressionContext:
                                                  det[0].ctypes.data_as(_dp), det[1].ctypes.data_as(_dp),
                                                  det[2].ctypes.data_as(_dp)))
         return base, rows, det
+
+    def set_tile_encode_workgroups(self, workgroups):
+        """mpc_context_set_tile_encode_workgroups: CUs the tile encode may fill (0 = all), for callers with other work on the device."""
+        _check(self.L.mpc_context_set_tile_encode_workgroups(self.h, int(workgroups)))
 
     @property
     def max_waves(self):

@@ -218,6 +218,7 @@ struct mpc_context {
     hipStream_t seq_up = nullptr, seq_compute = nullptr;
     bool seq_prioritised = false;                    // the side streams outrank the pursuits' (encode_sequence)
     int seq_workgroups = 0;                          // > 0: the pursuits of a frame sequence leave CUs to the kernels behind them
+    int user_workgroups = 0;                         // > 0: mpc_context_set_tile_encode_workgroups
     static constexpr int kSeqSlots = 6;              // frames in flight in mpc_encode_images (a frame's container is ready about
                                                      // three pursuits after its own started)
     int pipes_cap = 0;                               // > 0: at most this many concurrent sub-batches per call
@@ -378,6 +379,7 @@ mpc_status run_persistent(mpc_context* c, const mpc::FrameInput& in, const mpc::
     const int per_wg = mpc::pursuit_units_per_workgroup();
     int workgroups = static_cast<int>(std::min<long long>((n_units + per_wg - 1) / per_wg, d.workgroups));
     if (c->seq_workgroups > 0) workgroups = std::min(workgroups, c->seq_workgroups);
+    if (c->user_workgroups > 0) workgroups = std::min(workgroups, c->user_workgroups);
     const int forced = env_int("MPC_WORKGROUPS", 0);
     if (forced > 0) workgroups = std::min(forced, d.workgroups);
     std::lock_guard<std::mutex> hold(d.launch_lock);
@@ -639,6 +641,13 @@ int mpc_context_num_base(const mpc_context* c) { return c ? c->dict.num_base : 0
 int mpc_context_detail_rows(const mpc_context* c) { return c ? c->dict.total_detail_rows() : 0; }
 int mpc_context_device(const mpc_context* c) { return c ? c->device : -1; }
 int mpc_context_max_waves(const mpc_context* c) { return c ? c->max_waves : 0; }
+
+mpc_status mpc_context_set_tile_encode_workgroups(mpc_context* c, int workgroups) {
+    if (!c || workgroups < 0) return fail(MPC_ERR_ARGUMENT, "bad argument");
+    std::lock_guard<std::recursive_mutex> one_host_call(c->host_calls);
+    c->user_workgroups = workgroups;
+    return MPC_OK;
+}
 
 mpc_status mpc_context_set_fast(mpc_context* c, int on) {
     if (!c) return fail(MPC_ERR_ARGUMENT, "null context");

@@ -90,10 +90,12 @@ class StripedEncoder:
     """The N > 1 path on a GPU: stripe encode of every frame (one launch), stripe exchange (one batched send / receive over
     RCCL), the stripes copied to their places in the frame this rank owns (mpc_interleave_stripe_device), that frame -> container
     bytes (stream assembly and the per-symbol entropy work on the device, code tables on the host).  `step` does one step
-    synchronously; `run` pipelines consecutive steps.  Everything is enqueued on `stream`, which is made torch's current stream
-    for the duration (the process group orders its transfers against the current stream)."""
+    synchronously on `stream`; `run` pipelines consecutive steps over `stream` (the tile encodes, back to back) and a side stream
+    (everything behind a tile encode).  A stream is made torch's current stream while the exchange is enqueued on it (the process
+    group orders its transfers against the current stream)."""
 
-    SLOTS = 3
+    SLOTS = 3            # whole-frame records / container jobs in flight
+    STRIPE_SETS = 2      # stripe records: the exchange of step i reads one set while the tile encode of step i + 1 fills the other
 
     def __init__(self, ctx, width, height, frames, world, rank, backend):
         import torch
@@ -106,8 +108,8 @@ class StripedEncoder:
         self.begin, self.end = stripe_bounds(self.tiles_y, world, rank)
         per_frame = self.tiles_x * (self.end - self.begin)
         K = ctx.K
-        self.counts = torch.zeros((frames, per_frame, 3), dtype=torch.int16, device="cuda")
-        self.choices = torch.zeros((frames, per_frame, 3, K), dtype=torch.int32, device="cuda")
+        self.counts = [torch.zeros((frames, per_frame, 3), dtype=torch.int16, device="cuda") for _ in range(self.STRIPE_SETS)]
+        self.choices = [torch.zeros((frames, per_frame, 3, K), dtype=torch.int32, device="cuda") for _ in range(self.STRIPE_SETS)]
         tiles = self.tiles_x * self.tiles_y
         # whole-frame records of the frame this rank owns: a container job reads them until its `collect`
         self.frame_counts = [torch.zeros((tiles, 3), dtype=torch.int16, device="cuda") for _ in range(self.SLOTS)]
@@ -117,15 +119,21 @@ class StripedEncoder:
             rows = [stripe_bounds(self.tiles_y, world, r) for r in range(world)]
             self.recv = [[torch.empty((self.tiles_x * (e - b), 6), dtype=torch.uint8, device="cuda") for b, e in rows],
                          [torch.empty((self.tiles_x * (e - b), 3, K), dtype=torch.int32, device="cuda") for b, e in rows]]
+        self.side = None                                        # `run`'s second stream, made on first use
         ctx.reserve(frames * per_frame)
 
-    def _records_of_my_frame(self, d_rgb, stream, slot):
-        """stripe encode of every frame (one launch), stripe exchange, interleave into slot `slot`'s whole-frame records"""
+    def _encode_stripes(self, d_rgb, stream, stripe_set):
+        """stripe encode of every frame of the step, one launch"""
         W, H = self.W, self.H
         self.ctx.encode_batch_device(d_rgb.data_ptr(), self.world, W * H * 3, W, H, W * 3, self.begin, self.end,
-                                     self.counts.data_ptr(), self.choices.data_ptr(), stream=stream.cuda_stream)
-        cparts, hparts = exchange_stripes(self.dist, [list(self.counts.view(torch_uint8())), list(self.choices)], self.tiles_x,
-                                          self.tiles_y, self.via_cpu, self.recv)
+                                     self.counts[stripe_set].data_ptr(), self.choices[stripe_set].data_ptr(), stream=stream.cuda_stream)
+
+    def _gather_my_frame(self, stream, stripe_set, slot):
+        """stripe exchange, then the stripes copied to their places in slot `slot`'s whole-frame records; on torch's current
+        stream, which must be `stream`"""
+        W, H = self.W, self.H
+        cparts, hparts = exchange_stripes(self.dist, [list(self.counts[stripe_set].view(torch_uint8())), list(self.choices[stripe_set])],
+                                          self.tiles_x, self.tiles_y, self.via_cpu, self.recv)
         fc, fh = self.frame_counts[slot], self.frame_choices[slot]
         for r in range(self.world):
             b, e = stripe_bounds(self.tiles_y, self.world, r)
@@ -137,21 +145,49 @@ class StripedEncoder:
     def step(self, d_rgb, stream):
         import torch
         with torch.cuda.stream(stream):
-            counts, choices = self._records_of_my_frame(d_rgb, stream, 0)
+            self._encode_stripes(d_rgb, stream, 0)
+            counts, choices = self._gather_my_frame(stream, 0, 0)
             return self.ctx.records_to_container_device(counts.data_ptr(), choices.data_ptr(), self.W, self.H, stream=stream.cuda_stream)
 
     def run(self, d_rgb, stream, steps, views=False):
-        """`steps` steps, software-pipelined on ONE stream so that the device always has the next tile encode queued: step i's
-        encode + exchange + stream assembly + entropy phase 1 are enqueued, then step i-1's code tables are built on the host
-        (while the device works on step i) and its phase 2 + container copy enqueued behind, then step i-2's container is
-        collected (long finished).  Same containers as `step`, in order."""
+        """`steps` steps, software-pipelined over two streams.  `stream`: the tile encodes, one behind the other, on 7/8 of the
+        CUs (mpc_context_set_tile_encode_workgroups) so that what the side stream carries runs beside them instead of between
+        them.  Side stream: behind tile encode i (an event) the stripe exchange, the interleave, stream assembly + entropy
+        phase 1 of this rank's frame; behind those, once the host has built step i - 1's code tables (while the device works on
+        step i), its phase 2 + container copy.  Tile encode i + 2 waits (an event) until exchange and interleave i have read
+        the stripe set it will overwrite.  Step i - 2's container is collected at step i.  Same containers as `step`, in order."""
         import torch
         slots = self.SLOTS
+        if self.side is None:
+            self.side = torch.cuda.Stream(device=stream.device)
+        side = self.side
+        cus = self.ctx.max_waves // 12
+        self.ctx.set_tile_encode_workgroups(cus - cus // 8 if cus >= 16 else 0)
         out = []
-        with torch.cuda.stream(stream):
+        read = [None] * self.STRIPE_SETS                        # event: the side stream is through with this stripe set
+        encoded = {}
+
+        def enqueue_encode(k):
+            ss = k % self.STRIPE_SETS
+            if read[ss] is not None:
+                stream.wait_event(read[ss])
+            self._encode_stripes(d_rgb, stream, ss)
+            encoded[k] = torch.cuda.Event()
+            encoded[k].record(stream)
+
+        try:
+            side.wait_stream(stream)                            # whatever the caller enqueued before this call comes first
+            if steps >= 1:
+                enqueue_encode(0)
             for i in range(steps):
-                counts, choices = self._records_of_my_frame(d_rgb, stream, i % slots)       # slot i % 3 was collected at step i - 1
-                self.ctx.container_job_begin(i % slots, counts.data_ptr(), choices.data_ptr(), self.W, self.H, stream=stream.cuda_stream)
+                if i + 1 < steps:
+                    enqueue_encode(i + 1)                       # the next tile encode is queued before the host waits for anything
+                side.wait_event(encoded.pop(i))
+                with torch.cuda.stream(side):
+                    counts, choices = self._gather_my_frame(side, i % self.STRIPE_SETS, i % slots)   # slot i % 3 was collected at step i - 1
+                    read[i % self.STRIPE_SETS] = torch.cuda.Event()
+                    read[i % self.STRIPE_SETS].record(side)
+                    self.ctx.container_job_begin(i % slots, counts.data_ptr(), choices.data_ptr(), self.W, self.H, stream=side.cuda_stream)
                 if i >= 1:
                     self.ctx.container_job_tables((i - 1) % slots)
                 if i >= 2:
@@ -162,6 +198,16 @@ class StripedEncoder:
                 out.append(self.ctx.container_job_collect((steps - 2) % slots, views))
             if steps >= 1:
                 out.append(self.ctx.container_job_collect((steps - 1) % slots, views))
+            stream.wait_stream(side)                            # the caller's stream is behind everything this call enqueued
+        except BaseException:
+            for sl in range(slots):                             # no job may outlive the records it reads
+                try:
+                    self.ctx.container_job_cancel(sl)
+                except Exception:
+                    pass
+            raise
+        finally:
+            self.ctx.set_tile_encode_workgroups(0)
         return out
 
 

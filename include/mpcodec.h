@@ -87,6 +87,13 @@ int mpc_context_max_waves(const mpc_context* ctx);          /* resident waves of
  * float (sequential sums, products and sums rounded separately), bit-identical to oracle/mpo_fast.c and equivalent to the
  * double path in PSNR and size, not in bytes. */
 mpc_status mpc_context_set_fast(mpc_context* ctx, int on);
+
+/* How many CUs the tile encode (mpc_encode_tiles[_device], mpc_encode_batch_device) may fill: `workgroups` persistent
+ * workgroups, one per CU; 0 = all of them (the default).  For callers that keep other work on the device beside it -- a
+ * stripe exchange and the container jobs of the previous step (imageexperiments_amd/sharding.py: StripedEncoder.run) -- what
+ * mpc_encode_images[_device] does by itself for a frame sequence: leave one CU in eight, one per shader engine, free
+ * (mpc_context_max_waves / 12 = the CUs).  Not a reference interface: the reference has no device. */
+mpc_status mpc_context_set_tile_encode_workgroups(mpc_context* ctx, int workgroups);
 int mpc_context_is_fast(const mpc_context* ctx);
 
 /* quant[3*K]: Y then U then V */
