@@ -59,7 +59,11 @@ def load_library():
         getattr(L, "mpc_context_" + f).argtypes = [vp]
         getattr(L, "mpc_context_" + f).restype = C.c_int
     L.mpc_context_set_fast.argtypes = [vp, C.c_int]
-    L.mpc_context_set_tile_encode_workgroups.argtypes = [vp, C.c_int]
+    try:
+        L.mpc_context_set_tile_encode_workgroups.argtypes = [vp, C.c_int]
+    except AttributeError:
+        if not os.environ.get("MPCODEC_LIB"):             # an older build may be loaded for A/B timing only
+            raise
     L.mpc_context_is_fast.argtypes = [vp]
     L.mpc_context_is_fast.restype = C.c_int
     L.mpc_context_get_quant.argtypes = [vp, _dp]

@@ -38,7 +38,8 @@ struct Lane {
     mpc_context* ctx = nullptr;
     int device = -1;
     int begin = 0, end = 0;                       // this lane's tile rows
-    hipStream_t stream = nullptr, up_stream = nullptr;
+    hipStream_t stream = nullptr, up_stream = nullptr;     // the tile encodes; the uploads
+    hipStream_t side = nullptr;                          // everything behind a tile encode: pulls, interleave, the container job
     uint8_t* d_rgb[2] = {nullptr, nullptr};       // [frames of a step][H][W][3]; only this lane's rows are ever written; by step parity
     uint8_t* h_rgb[2] = {nullptr, nullptr};       // pinned: this lane's rows of the frames of a step
     uint16_t* d_counts[2] = {nullptr, nullptr};   // this lane's stripes of a step's frames [frame][tiles_x * rows][3]; by step parity
@@ -72,6 +73,7 @@ void release(Lane& l) {
     (void)hipSetDevice(l.device);
     if (l.stream) (void)hipStreamSynchronize(l.stream);
     if (l.up_stream) (void)hipStreamSynchronize(l.up_stream);
+    if (l.side) (void)hipStreamSynchronize(l.side);
     for (int p = 0; p < 2; ++p) {
         (void)hipFree(l.d_rgb[p]); (void)hipFree(l.d_counts[p]); (void)hipFree(l.d_choices[p]);
         if (l.h_rgb[p]) (void)hipHostFree(l.h_rgb[p]);
@@ -84,6 +86,7 @@ void release(Lane& l) {
     for (int j = 0; j < 3; ++j) { (void)hipFree(l.d_frame_counts[j]); (void)hipFree(l.d_frame_choices[j]); }
     if (l.stream) (void)hipStreamDestroy(l.stream);
     if (l.up_stream) (void)hipStreamDestroy(l.up_stream);
+    if (l.side) (void)hipStreamDestroy(l.side);
 }
 
 }  // namespace
@@ -121,7 +124,8 @@ extern "C" mpc_status mpc_encode_images_multi(mpc_context* const* ctxs, int n_de
         const size_t stripe_tiles = static_cast<size_t>(tiles_x) * (l.end - l.begin);
         const int y0 = l.begin * 8, y1 = std::min(height, l.end * 8);
         bool ok = hipSetDevice(l.device) == hipSuccess && hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) == hipSuccess &&
-                  hipStreamCreateWithFlags(&l.up_stream, hipStreamNonBlocking) == hipSuccess;
+                  hipStreamCreateWithFlags(&l.up_stream, hipStreamNonBlocking) == hipSuccess &&
+                  hipStreamCreateWithFlags(&l.side, hipStreamNonBlocking) == hipSuccess;
         for (int p = 0; p < 2 && ok; ++p) {
             ok = hipMalloc(reinterpret_cast<void**>(&l.d_rgb[p]), frame_bytes * N) == hipSuccess &&
                  hipHostMalloc(reinterpret_cast<void**>(&l.h_rgb[p]), row_bytes * (y1 - y0) * N, hipHostMallocDefault) == hipSuccess &&
@@ -187,6 +191,16 @@ extern "C" mpc_status mpc_encode_images_multi(mpc_context* const* ctxs, int n_de
         const int y0 = me.begin * 8, y1 = std::min(height, me.end * 8);
         const size_t band = row_bytes * (y1 - y0);                       // my rows of one frame
         if (hipSetDevice(me.device) != hipSuccess) { fail(text("lane %d: hipSetDevice failed", r)); return; }
+        // The tile encodes follow each other on `stream`, on 7/8 of the CUs; the pulls, the interleave and the container job of a
+        // step run on `side`, beside the next step's tile encode (as in the single-device frame pipeline).
+        struct Workgroups {
+            mpc_context* ctx;
+            ~Workgroups() { (void)mpc_context_set_tile_encode_workgroups(ctx, 0); }
+        } workgroups{me.ctx};
+        {
+            const int cus = mpc_context_max_waves(me.ctx) / 12;
+            if (cus >= 16) (void)mpc_context_set_tile_encode_workgroups(me.ctx, cus - cus / 8);
+        }
         // my rows of the frames of step s -> pinned memory (a few threads) -> the device, on the upload stream
         auto upload = [&](long s) -> bool {
             const int par = static_cast<int>(s & 1);
@@ -217,8 +231,7 @@ extern "C" mpc_status mpc_encode_images_multi(mpc_context* const* ctxs, int n_de
                 // the stripes of step s - 2 (same buffers) must have been pulled by their owners before this encode overwrites them
                 bool ok = true;
                 if (s >= 2)
-                    for (int o = 0; o < N && ok; ++o) {
-                        if (o == r) continue;
+                    for (int o = 0; o < N && ok; ++o) {                  // o == r: my own side stream has interleaved my stripe
                         ok = await(lanes[static_cast<size_t>(o)].pulled_step, s - 2);
                         if (ok && hipStreamWaitEvent(me.stream, lanes[static_cast<size_t>(o)].pulled[par], 0) != hipSuccess) ok = false;
                     }
@@ -231,30 +244,31 @@ extern "C" mpc_status mpc_encode_images_multi(mpc_context* const* ctxs, int n_de
                 // as the owner of frame r of this step: every lane's stripe of it -> whole-frame records -> container job
                 if (r < n_g) {
                     const int slot = static_cast<int>(s % 3);
+                    LANE_HIP(hipStreamWaitEvent(me.side, me.encoded[par], 0));
                     for (int q = 0; q < N && ok; ++q) {
                         Lane& src = lanes[static_cast<size_t>(q)];
                         const size_t src_tiles = static_cast<size_t>(tiles_x) * (src.end - src.begin);
                         const uint16_t* part_counts = src.d_counts[par] + 3 * src_tiles * r;
                         const mpc_basis_choice* part_choices = src.d_choices[par] + 3 * static_cast<size_t>(K) * src_tiles * r;
                         if (q != r) {
-                            ok = await(src.encoded_step, s) && hipStreamWaitEvent(me.stream, src.encoded[par], 0) == hipSuccess &&
+                            ok = await(src.encoded_step, s) && hipStreamWaitEvent(me.side, src.encoded[par], 0) == hipSuccess &&
                                  hipMemcpyPeerAsync(me.d_part_counts[static_cast<size_t>(q)], me.device, part_counts, src.device,
-                                                    sizeof(uint16_t) * 3 * src_tiles, me.stream) == hipSuccess &&
+                                                    sizeof(uint16_t) * 3 * src_tiles, me.side) == hipSuccess &&
                                  hipMemcpyPeerAsync(me.d_part_choices[static_cast<size_t>(q)], me.device, part_choices, src.device,
-                                                    sizeof(mpc_basis_choice) * 3 * K * src_tiles, me.stream) == hipSuccess;
+                                                    sizeof(mpc_basis_choice) * 3 * K * src_tiles, me.side) == hipSuccess;
                             part_counts = me.d_part_counts[static_cast<size_t>(q)];
                             part_choices = me.d_part_choices[static_cast<size_t>(q)];
                         }
                         if (ok && mpc_interleave_stripe_device(me.ctx, part_counts, part_choices, width, height, src.begin, src.end,
-                                                               me.d_frame_counts[slot], me.d_frame_choices[slot], me.stream) != MPC_OK)
+                                                               me.d_frame_counts[slot], me.d_frame_choices[slot], me.side) != MPC_OK)
                             ok = false;
                     }
                     if (!ok) { if (!failed) fail(text("lane %d: pulling the stripes of step %ld failed: %s", r, s, mpc_last_error())); break; }
-                    LANE_HIP(hipEventRecord(me.pulled[par], me.stream));
+                    LANE_HIP(hipEventRecord(me.pulled[par], me.side));
                     me.pulled_step.store(s, std::memory_order_release);
-                    LANE_MPC(mpc_container_job_begin(me.ctx, slot, me.d_frame_counts[slot], me.d_frame_choices[slot], width, height, quant, me.stream));
+                    LANE_MPC(mpc_container_job_begin(me.ctx, slot, me.d_frame_counts[slot], me.d_frame_choices[slot], width, height, quant, me.side));
                 } else {
-                    LANE_HIP(hipEventRecord(me.pulled[par], me.stream));             // nothing to pull: the event is there for the waiters
+                    LANE_HIP(hipEventRecord(me.pulled[par], me.side));               // nothing to pull: the event is there for the waiters
                     me.pulled_step.store(s, std::memory_order_release);
                 }
                 (void)stripe_tiles;
@@ -271,6 +285,7 @@ extern "C" mpc_status mpc_encode_images_multi(mpc_context* const* ctxs, int n_de
 #undef LANE_HIP
 #undef LANE_MPC
         (void)hipStreamSynchronize(me.stream);
+        (void)hipStreamSynchronize(me.side);
         (void)hipStreamSynchronize(me.up_stream);
     };
 
