@@ -217,8 +217,9 @@ struct mpc_context {
     // mpc_encode_images: upload / compute / download streams and per-slot events (upload done, pursuit done, download done)
     hipStream_t seq_up = nullptr, seq_compute = nullptr;
     bool seq_prioritised = false;                    // the side streams outrank the pursuits' (encode_sequence)
-    int seq_workgroups = 0;                          // > 0: the pursuits of a frame sequence leave CUs to the kernels behind them
-    int user_workgroups = 0;                         // > 0: mpc_context_set_tile_encode_workgroups
+    // read by device-pointer encodes, which do not take `host_calls`: a stale value costs or gains a few workgroups, nothing else
+    std::atomic<int> seq_workgroups{0};              // > 0: the pursuits of a frame sequence leave CUs to the kernels behind them
+    std::atomic<int> user_workgroups{0};             // > 0: mpc_context_set_tile_encode_workgroups
     static constexpr int kSeqSlots = 6;              // frames in flight in mpc_encode_images (a frame's container is ready about
                                                      // three pursuits after its own started)
     int pipes_cap = 0;                               // > 0: at most this many concurrent sub-batches per call
@@ -378,8 +379,8 @@ mpc_status run_persistent(mpc_context* c, const mpc::FrameInput& in, const mpc::
     // queues run dry (mp_pursuit.hip: channel switch), so a small frame spreads over the channels by itself.
     const int per_wg = mpc::pursuit_units_per_workgroup();
     int workgroups = static_cast<int>(std::min<long long>((n_units + per_wg - 1) / per_wg, d.workgroups));
-    if (c->seq_workgroups > 0) workgroups = std::min(workgroups, c->seq_workgroups);
-    if (c->user_workgroups > 0) workgroups = std::min(workgroups, c->user_workgroups);
+    if (const int limit = c->seq_workgroups.load(std::memory_order_relaxed); limit > 0) workgroups = std::min(workgroups, limit);
+    if (const int limit = c->user_workgroups.load(std::memory_order_relaxed); limit > 0) workgroups = std::min(workgroups, limit);
     const int forced = env_int("MPC_WORKGROUPS", 0);
     if (forced > 0) workgroups = std::min(forced, d.workgroups);
     std::lock_guard<std::mutex> hold(d.launch_lock);

@@ -442,6 +442,22 @@ def test_launch_configurations_do_not_change_records(gpu, oracle, monkeypatch, e
     ctx.close()
 
 
+@pytest.mark.parametrize("workgroups", [1, 7, 224, 0])
+def test_workgroup_limit_does_not_change_records(gpu, oracle, workgroups):
+    """mpc_context_set_tile_encode_workgroups: the tile encode on fewer CUs (what a frame sequence and the multi-GPU drivers do
+    to leave room for the kernels behind it) finds the same records; 0 gives all CUs back"""
+    import imageexperiments_amd as ia
+    rgb = oracle.synth_frame(328, 208, 77)
+    ctx = ia.create_compression_context(16, 8, 3.0, device=0)
+    octx = oracle.OracleContext(16, 8, 3.0)
+    ctx.set_tile_encode_workgroups(workgroups)
+    _compare(ctx.encode_tiles(rgb), octx.encode_tiles(rgb), 16)
+    assert bytes(ctx.encode_image(rgb)) == bytes(octx.encode_image(rgb))
+    with pytest.raises(ia.MpcError):
+        ctx.set_tile_encode_workgroups(-1)
+    ctx.close()
+
+
 @pytest.mark.parametrize("K", [1, 8, 32])
 def test_degenerate_frames_bytes_equal_oracle(gpu, oracle, K):
     """Flat frames (black: every residual is zero from the start; white and grey: only the DC atom matters), one-pixel
