@@ -75,6 +75,9 @@ struct FrameInput {
     int frames;
     long long frame_stride;
     int tile_row_begin, tile_rows, tiles_x;
+    int out_tile_rows;               // 0: records in stripe order (tile tx * tile_rows + ty - tile_row_begin); > 0: in the order of a
+                                     // whole frame of this many tile rows (tx * out_tile_rows + ty): stripes encoded one by one
+                                     // land where one launch over the frame would put them
     // vector mode (matching::CalcMPDynamic on caller vectors): vec_in != nullptr
     const double* vec_in;            // [n][64]
     int vec_channel;
@@ -150,6 +153,7 @@ struct PursuitArgs {
     int width, height;
     long long row_stride, frame_stride;
     int tile_row_begin, tile_rows, tiles_x;
+    int out_tile_rows;               // FrameInput::out_tile_rows
     int rgb_aligned8;                // rgb, row_stride and frame_stride are multiples of 8: whole tiles are read as 8-byte words
     const double* vec_in;
     int vec_channel;

@@ -503,6 +503,7 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void mp_pursuit_kernel(con
                 const int frame = (int)(ts / tiles_per_frame);
                 const int tile = (int)(ts - (long long)frame * tiles_per_frame);
                 const int tx = tile / a.tile_rows, ty = a.tile_row_begin + (tile - tx * a.tile_rows);
+                if (a.out_tile_rows > 0) s.t = (frame * a.tiles_x + tx) * a.out_tile_rows + ty;      // the records' place in a whole frame
                 const uint8_t* img = a.rgb + (long long)frame * a.frame_stride;
                 unsigned char px[16][3];
                 // the lane's 16 pixels are two rows of 8 (24 bytes each, at 24 tx: 8-byte aligned when the rows are).  Whole tiles

@@ -224,6 +224,8 @@ struct mpc_context {
                                                      // three pursuits after its own started)
     int pipes_cap = 0;                               // > 0: at most this many concurrent sub-batches per call
     hipEvent_t seq_events[kSeqSlots][3] = {};
+    static constexpr int kSingleStripes = 4;
+    hipEvent_t seq_stripe_up[kSingleStripes] = {};   // a single host frame goes up and is encoded in row stripes (encode_sequence)
     hipEvent_t seq_pursuit_done[kSeqSlots] = {};      // behind a slot's pursuit, for the slot's own stream to wait on
     hipStream_t seq_down[kSeqSlots] = {};             // one download stream per slot: its worker thread drives it
     // device-side entropy stage (mp_entropy.hip): per-slot buffers (grow-only) and the histogram tables all slots share
@@ -419,6 +421,7 @@ mpc_status run_persistent(mpc_context* c, const mpc::FrameInput& in, const mpc::
     a.tile_row_begin = in.tile_row_begin;
     a.tile_rows = in.tile_rows;
     a.tiles_x = in.tiles_x;
+    a.out_tile_rows = in.out_tile_rows;
     a.rgb_aligned8 = (reinterpret_cast<uintptr_t>(in.rgb) % 8 == 0 && in.row_stride % 8 == 0 && (in.frames <= 1 || in.frame_stride % 8 == 0)) ? 1 : 0;
     a.vec_in = in.vec_in;
     a.vec_channel = in.vec_channel;
@@ -621,6 +624,8 @@ void mpc_context_destroy(mpc_context* c) {
                 if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : c->seq_pursuit_done)
             if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : c->seq_stripe_up)
+            if (e) (void)hipEventDestroy(e);
         for (auto& p : c->pipes) {
             if (p.mem) (void)hipFree(p.mem);
             if (p.stream) (void)hipStreamDestroy(p.stream);
@@ -685,10 +690,26 @@ mpc_status mpc_context_get_dictionary(const mpc_context* c, double* base, int32_
     return MPC_OK;
 }
 
+// whole_frame_order: the records go where one launch over the whole frame would put them (FrameInput::out_tile_rows) and the
+// caller has zeroed d_choices for the whole frame (stripes of one frame encoded one by one, encode_sequence's single frames)
+static mpc_status encode_batch_device(mpc_context* c, const uint8_t* d_rgb, int frames, size_t frame_stride, int width,
+                                      int height, size_t row_stride, int tile_row_begin, int tile_row_end,
+                                      const double* quant, uint16_t* d_counts, mpc_basis_choice* d_choices,
+                                      double* d_energy, uint32_t* d_swept, void* stream, bool whole_frame_order);
+
 mpc_status mpc_encode_batch_device(mpc_context* c, const uint8_t* d_rgb, int frames, size_t frame_stride, int width,
                                    int height, size_t row_stride, int tile_row_begin, int tile_row_end,
                                    const double* quant, uint16_t* d_counts, mpc_basis_choice* d_choices,
                                    double* d_energy, uint32_t* d_swept, int waves, void* stream) {
+    (void)waves;
+    return encode_batch_device(c, d_rgb, frames, frame_stride, width, height, row_stride, tile_row_begin, tile_row_end, quant, d_counts,
+                               d_choices, d_energy, d_swept, stream, false);
+}
+
+static mpc_status encode_batch_device(mpc_context* c, const uint8_t* d_rgb, int frames, size_t frame_stride, int width,
+                                      int height, size_t row_stride, int tile_row_begin, int tile_row_end,
+                                      const double* quant, uint16_t* d_counts, mpc_basis_choice* d_choices,
+                                      double* d_energy, uint32_t* d_swept, void* stream, bool whole_frame_order) {
     if (!c) return fail(MPC_ERR_ARGUMENT, "null context");
     if (c->device < 0) return fail(MPC_ERR_NO_DEVICE, "context was created without a device; there is no CPU fallback");
     if (!d_rgb || !d_counts || !d_choices) return fail(MPC_ERR_ARGUMENT, "null buffer");
@@ -705,7 +726,7 @@ mpc_status mpc_encode_batch_device(mpc_context* c, const uint8_t* d_rgb, int fra
     HIP_TRY(hipSetDevice(c->device));
     const double* d_q = nullptr;
     if (const mpc_status qs = call_quant(c, quant, s, &d_q); qs != MPC_OK) return qs;
-    HIP_TRY(hipMemsetAsync(d_choices, 0, sizeof(mpc_basis_choice) * tiles * 3 * c->K, s));
+    if (!whole_frame_order) HIP_TRY(hipMemsetAsync(d_choices, 0, sizeof(mpc_basis_choice) * tiles * 3 * c->K, s));
     mpc::FrameInput in{};
     in.rgb = d_rgb;
     in.width = width;
@@ -716,6 +737,7 @@ mpc_status mpc_encode_batch_device(mpc_context* c, const uint8_t* d_rgb, int fra
     in.tile_row_begin = tile_row_begin;
     in.tile_rows = tile_row_end - tile_row_begin;
     in.tiles_x = tiles_x;
+    in.out_tile_rows = whole_frame_order ? tiles_y : 0;
     in.vec_in = nullptr;
     in.vec_channel = 0;
     mpc::Outputs out{};
@@ -723,7 +745,6 @@ mpc_status mpc_encode_batch_device(mpc_context* c, const uint8_t* d_rgb, int fra
     out.choices = reinterpret_cast<uint32_t*>(d_choices);
     out.energy = d_energy;
     out.swept = d_swept;
-    (void)waves;
     return run_pursuit(c, in, out, d_q, tiles * 3, stream);
 }
 
@@ -1502,6 +1523,7 @@ static mpc_status encode_sequence(mpc_context* c, const uint8_t* const* frames, 
         for (auto& s : c->seq_down)
             HIP_TRY(prio ? hipStreamCreateWithPriority(&s, hipStreamNonBlocking, greatest) : hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
         for (hipEvent_t& e : c->seq_pursuit_done) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (hipEvent_t& e : c->seq_stripe_up) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         // blocking events: a thread waiting for the device sleeps instead of spinning (the entropy stage wants the cores)
         for (auto& slot : c->seq_events)
             for (hipEvent_t& e : slot) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventBlockingSync));
@@ -1605,7 +1627,16 @@ static mpc_status encode_sequence(mpc_context* c, const uint8_t* const* frames, 
             return e;
         });
     };
-    if (!on_device) start_upload(0);
+    // a single host frame in row stripes (below): MPC_SINGLE_STRIPES, 1 = whole frame at once; needs the persistent kernel (the
+    // step-synchronous cross-check path writes stripe order only)
+    const int stripes_env = std::min<int>(mpc_context::kSingleStripes, std::max(1, env_int("MPC_SINGLE_STRIPES", 0)));
+    // measured (tools/single_frame_trace.py, host RGB -> bytes): 4928x3264  1 / 2 / 3 / 4 stripes: 5.69 / 5.25 / 4.92 / 5.20 ms;
+    // 1920x1080: 1.24 / 1.42 / 1.45 / 1.63 ms -- every further launch costs a prologue (144 KiB of LDS per workgroup) and a tail,
+    // more than a 6 MB copy takes
+    // 7680x4320: 9.5 / 8.3 / 8.1 ms with 1 / 3 / 4
+    const int single_stripes = env_int("MPC_SINGLE_STRIPES", 0) > 0 ? stripes_env : (img_bytes >= (size_t(80) << 20) ? 4 : (img_bytes >= (size_t(32) << 20) ? 3 : 1));
+    const bool striped_single = single && !on_device && single_stripes > 1 && tiles_y >= 4 * single_stripes && !steps_path();
+    if (!on_device && !striped_single) start_upload(0);
     for (int f = 0; f < n_frames && st == MPC_OK; ++f) {
         const int sl = f % static_cast<int>(slots);
         Pending& slot = pending[sl];
@@ -1629,7 +1660,8 @@ static mpc_status encode_sequence(mpc_context* c, const uint8_t* const* frames, 
         char* dbase = static_cast<char*>(c->stage) + static_cast<size_t>(sl) * dev_slot;
         char* hbase = static_cast<char*>(c->host_stage) + static_cast<size_t>(sl) * host_slot;
         const uint8_t* d_rgb = frames[f];
-        if (!on_device) {
+        bool encoded_in_stripes = false;
+        if (!on_device && !striped_single) {
             uint8_t* d_img = reinterpret_cast<uint8_t*>(dbase);
             dbase += up(img_bytes);
             hbase += up(img_bytes);
@@ -1638,6 +1670,45 @@ static mpc_status encode_sequence(mpc_context* c, const uint8_t* const* frames, 
             if (f + 1 < n_frames) start_upload(f + 1);
             if (st != MPC_OK) break;
             d_rgb = d_img;
+        }
+        if (striped_single) {
+            // One frame from host memory: nothing to overlap its upload with but its own tile encode.  The frame goes up in row
+            // stripes and each stripe's tile encode starts behind its own copy (an event), writing its records where one launch
+            // over the whole frame would put them: the copy of stripe s + 1 runs beside the encode of stripe s.
+            uint8_t* d_img = reinterpret_cast<uint8_t*>(dbase);
+            uint8_t* pinned_rgb = reinterpret_cast<uint8_t*>(hbase);
+            dbase += up(img_bytes);
+            hbase += up(img_bytes);
+            uint16_t* d_counts_s = reinterpret_cast<uint16_t*>(dbase);
+            mpc_basis_choice* d_choices_s = reinterpret_cast<mpc_basis_choice*>(dbase + counts_bytes);
+            MPC_SEQ_TRY(hipMemsetAsync(d_choices_s, 0, sizeof(mpc_basis_choice) * n_tc * K, pursuit_stream));
+            const uint8_t* src = frames[f];
+            const size_t row_bytes = static_cast<size_t>(3) * width;
+            for (int sp = 0; sp < single_stripes && st == MPC_OK; ++sp) {
+                const int rb = static_cast<int>(static_cast<long long>(tiles_y) * sp / single_stripes);
+                const int re = static_cast<int>(static_cast<long long>(tiles_y) * (sp + 1) / single_stripes);
+                const size_t lo_b = row_bytes * static_cast<size_t>(8 * rb), hi_b = row_bytes * static_cast<size_t>(std::min(height, 8 * re));
+                const size_t chunk = std::max<size_t>(size_t(1) << 20, (((hi_b - lo_b + 7) / 8) + 4095) & ~static_cast<size_t>(4095));
+                const int chunks = static_cast<int>((hi_b - lo_b + chunk - 1) / chunk);
+                std::atomic<int> failed{static_cast<int>(hipSuccess)};
+                const int device = c->device;
+                hipStream_t up_stream = c->seq_up;
+                mpc::parallel_io_jobs(chunks, 8, [&](int k) {
+                    const size_t lo = lo_b + chunk * static_cast<size_t>(k), hi = std::min(hi_b, lo + chunk);
+                    std::memcpy(pinned_rgb + lo, src + lo, hi - lo);
+                    hipError_t e = hipSetDevice(device);
+                    if (e == hipSuccess) e = hipMemcpyAsync(d_img + lo, pinned_rgb + lo, hi - lo, hipMemcpyHostToDevice, up_stream);
+                    if (e != hipSuccess) failed.store(static_cast<int>(e));
+                });
+                MPC_SEQ_TRY(static_cast<hipError_t>(failed.load()));
+                MPC_SEQ_TRY(hipEventRecord(c->seq_stripe_up[sp], up_stream));
+                MPC_SEQ_TRY(hipStreamWaitEvent(pursuit_stream, c->seq_stripe_up[sp], 0));
+                st = encode_batch_device(c, d_img, 1, 0, width, height, row_bytes, rb, re, quant, d_counts_s, d_choices_s, nullptr, nullptr,
+                                         pursuit_stream, true);
+            }
+            if (st != MPC_OK) break;
+            d_rgb = d_img;
+            encoded_in_stripes = true;
         }
         uint16_t* d_counts = reinterpret_cast<uint16_t*>(dbase);
         mpc_basis_choice* d_choices = reinterpret_cast<mpc_basis_choice*>(dbase + counts_bytes);
@@ -1654,8 +1725,9 @@ static mpc_status encode_sequence(mpc_context* c, const uint8_t* const* frames, 
         uint16_t* counts = reinterpret_cast<uint16_t*>(hbase);
         unsigned long long* off = reinterpret_cast<unsigned long long*>(hbase + counts_bytes);
         uint16_t* symbols = reinterpret_cast<uint16_t*>(hbase + counts_bytes + off_bytes);
-        st = mpc_encode_tiles_device(c, d_rgb, width, height, static_cast<size_t>(3) * width, 0, tiles_y, quant, d_counts, d_choices,
-                                     nullptr, nullptr, 0, pursuit_stream);
+        if (!encoded_in_stripes)
+            st = mpc_encode_tiles_device(c, d_rgb, width, height, static_cast<size_t>(3) * width, 0, tiles_y, quant, d_counts, d_choices,
+                                         nullptr, nullptr, 0, pursuit_stream);
         if (st != MPC_OK) break;
         // Two side streams for all slots (MPC_SHARED_SIDE_STREAMS=0: one per slot): the runtime maps streams onto a handful
         // of hardware queues, and a slot stream that lands on the pursuit stream's queue lines its kernels up behind the next

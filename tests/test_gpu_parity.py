@@ -458,6 +458,20 @@ def test_workgroup_limit_does_not_change_records(gpu, oracle, workgroups):
     ctx.close()
 
 
+@pytest.mark.parametrize("stripes", [2, 3, 4])
+def test_single_host_frame_in_row_stripes_bytes_equal_oracle(gpu, oracle, monkeypatch, stripes):
+    """mpc_encode_image from host memory uploads and encodes a large frame in row stripes (each stripe's tile encode behind its own
+    copy, records written in whole-frame order); forced here on small frames, ragged edges included"""
+    import imageexperiments_amd as ia
+    monkeypatch.setenv("MPC_SINGLE_STRIPES", str(stripes))
+    ctx = ia.create_compression_context(16, 8, 3.0, device=0)
+    octx = oracle.OracleContext(16, 8, 3.0)
+    for (w, h, seed) in ((328, 208, 5), (203, 517, 6), (64, 136, 7)):
+        rgb = oracle.synth_frame(w, h, seed)
+        assert bytes(ctx.encode_image(rgb)) == bytes(octx.encode_image(rgb)), (w, h, stripes)
+    ctx.close()
+
+
 @pytest.mark.parametrize("K", [1, 8, 32])
 def test_degenerate_frames_bytes_equal_oracle(gpu, oracle, K):
     """Flat frames (black: every residual is zero from the start; white and grey: only the DC atom matters), one-pixel
