@@ -1548,23 +1548,14 @@ static mpc_status encode_sequence(mpc_context* c, const uint8_t* const* frames, 
         static const int env_wg = env_int("MPC_SEQ_WORKGROUPS", -1);
         c->seq_workgroups = env_wg >= 0 ? env_wg : c->num_cus - c->num_cus / 8;
     }
-    // ONE ordered device queue.  The pursuit kernel fills every CU for milliseconds, and nothing else gets onto the device
-    // while it runs -- not a small kernel, not a copy (short copies are blit kernels) -- so work queued beside it on another
-    // stream just waits for a gap at a time nobody controls.  Everything therefore goes to seq_compute in the order it should
-    // run: pursuit(f), stream assembly(f), entropy phase 1(f) from this thread; phase 2(f) and the container's copy from the
-    // frame's worker once it has built the tables -- which happens while pursuit(f + 1) runs; pursuit(f + 2) is enqueued only
-    // after that (`phase2_enqueued`), so that it cannot slip in front.  The statistics reach the host through mapped memory
-    // written by the kernels themselves, the host waits on events only.
-    // Phase 2(f - 1) and the stream assembly + phase 1 of frame f are both chains of small, latency-bound kernels that fall into the
-    // same gap between two pursuits: phase 2 goes to its slot's own stream so that the two chains overlap, and the next pursuit
-    // waits for both (MPC_PHASE2_BESIDE=0: one stream for everything).
+    // The pipeline's streams.  `seq_compute`: the pursuits, one behind the other.  Side stream A: behind pursuit(f) (an event) the
+    // stream assembly and entropy phase 1 of frame f.  Side stream B: phase 2 and the container's copy of frame f, enqueued by the
+    // frame's worker once it has built the code tables from phase 1's statistics (mapped host memory written by the kernels
+    // themselves; the host waits on events only).  Pursuit(f) waits (events) for the assembly + phase 1 of frame f - 2 and for
+    // the phase 2 of frame f - 3, so nothing piles up; with the CUs the pursuits leave free (above) both chains run beside the
+    // pursuits of the following frames.  The shapes this replaced -- everything on one ordered queue; phase 2 alone on a side
+    // stream -- are in DESIGN.md 4 and 9.
     hipStream_t pursuit_stream = c->seq_compute;
-    static const bool phase2_beside = env_int("MPC_PHASE2_BESIDE", 1) != 0;
-    // One step further (MPC_ASSEMBLY_BESIDE, needs the above): the stream assembly + phase 1 of frame f go to the slot's stream as
-    // well, and pursuit(f + 1) starts right behind pursuit(f).  A pursuit's last millisecond leaves more and more CUs idle (its
-    // chroma workgroups run out of tile-channels one by one); the small kernels of frames f - 1 (assembly, phase 1) and f - 2
-    // (phase 2, copy) fill that tail.  Pursuit(f) waits for the assembly of f - 2 and the phase 2 of f - 3, so nothing piles up.
-    static const bool assembly_beside = phase2_beside && env_int("MPC_ASSEMBLY_BESIDE", 1) != 0;
     std::future<void> phase2_enqueued[S];
     EntropyBuffers ent[S];
     if (device_entropy)
@@ -1643,19 +1634,20 @@ static mpc_status encode_sequence(mpc_context* c, const uint8_t* const* frames, 
         collect(slot);                    // frame f - slots is done with this slot: its download and its entropy stage have finished
         if (st != MPC_OK) break;
         // how far the pursuits may run ahead of the small kernels behind them: pursuit(f) waits for the stream assembly + phase 1
-        // of frame f - lag_assembly and for the phase 2 of frame f - back.  These chains only get CUs where a pursuit leaves some;
-        // measured (tools/ab_env_bench.sh, 4928x3264): lags 2 / 3 -> 4 660 Mpix/s, 3 / 3 -> 4 610 - 4 690, 3 / 4 -> 4 000 - 4 300,
-        // 4 / 5 -> 4 090 - 4 680: more slack lets the chains of several frames pile up in front of one pursuit's end.
+        // of frame f - lag_assembly and for the phase 2 of frame f - back.  Measured (tools/ab_env_bench.sh, 4928x3264) while the
+        // pursuits still filled every CU: lags 2 / 3 -> 4 660 Mpix/s, 3 / 3 -> 4 610 - 4 690, 3 / 4 -> 4 000 - 4 300, 4 / 5 -> 4 090 -
+        // 4 680 (more slack let the chains of several frames pile up in front of one pursuit's end); with CUs left free for the
+        // chains 2 / 2, 2 / 3 and 3 / 4 are within 1 % of each other.
         static const int lag_assembly = std::min(4, std::max(2, env_int("MPC_LAG_ASSEMBLY", 2)));
         static const int lag_phase2 = std::min(5, std::max(lag_assembly, env_int("MPC_LAG_PHASE2", 3)));
-        const int back = assembly_beside ? lag_phase2 : 2;
+        const int back = lag_phase2;
         if (f >= back && phase2_enqueued[(f - back) % static_cast<int>(slots)].valid()) {
             // frame f - back's phase 2 is on its slot's stream by now: this frame's pursuit starts behind it (the event is the one
             // its worker recorded behind the container's copy; on the host route it is an old one and the wait is empty)
             phase2_enqueued[(f - back) % static_cast<int>(slots)].get();
-            if (phase2_beside) MPC_SEQ_TRY(hipStreamWaitEvent(pursuit_stream, c->seq_events[(f - back) % static_cast<int>(slots)][2], 0));
+            MPC_SEQ_TRY(hipStreamWaitEvent(pursuit_stream, c->seq_events[(f - back) % static_cast<int>(slots)][2], 0));
         }
-        if (assembly_beside && f >= lag_assembly)
+        if (f >= lag_assembly)
             MPC_SEQ_TRY(hipStreamWaitEvent(pursuit_stream, c->seq_events[(f - lag_assembly) % static_cast<int>(slots)][1], 0));
         char* dbase = static_cast<char*>(c->stage) + static_cast<size_t>(sl) * dev_slot;
         char* hbase = static_cast<char*>(c->host_stage) + static_cast<size_t>(sl) * host_slot;
@@ -1731,7 +1723,7 @@ static mpc_status encode_sequence(mpc_context* c, const uint8_t* const* frames, 
         if (st != MPC_OK) break;
         // Two side streams for all slots (MPC_SHARED_SIDE_STREAMS=0: one per slot): the runtime maps streams onto a handful
         // of hardware queues, and a slot stream that lands on the pursuit stream's queue lines its kernels up behind the next
-        // pursuit -- with three streams in all nothing has to share.  `side_a`: stream assembly + phase 1 (assembly_beside);
+        // pursuit -- with three streams in all nothing has to share.  `side_a`: stream assembly + phase 1;
         // `down`: phase 2, the container's copy, the host route's copies.
         // Measured in round 2 (all streams at one priority): per-slot streams are 4 % faster on 16 Mpixel frames (4 440 against
         // 4 270 Mpix/s) and bimodal on 2 Mpixel frames, where the chains are as long as the pursuit's tail (2 960 or 2 260 Mpix/s
@@ -1741,11 +1733,9 @@ static mpc_status encode_sequence(mpc_context* c, const uint8_t* const* frames, 
         const bool shared_sides = shared_env >= 0 ? shared_env != 0 : (c->seq_prioritised || tiles < 100000);
         hipStream_t side_a = shared_sides ? c->seq_down[0] : c->seq_down[sl];
         hipStream_t down = shared_sides ? c->seq_down[1] : c->seq_down[sl];
-        hipStream_t behind = assembly_beside ? side_a : pursuit_stream;
-        if (assembly_beside) {
-            MPC_SEQ_TRY(hipEventRecord(c->seq_pursuit_done[sl], pursuit_stream));
-            MPC_SEQ_TRY(hipStreamWaitEvent(side_a, c->seq_pursuit_done[sl], 0));
-        }
+        hipStream_t behind = side_a;
+        MPC_SEQ_TRY(hipEventRecord(c->seq_pursuit_done[sl], pursuit_stream));
+        MPC_SEQ_TRY(hipStreamWaitEvent(side_a, c->seq_pursuit_done[sl], 0));
         MPC_SEQ_TRY(static_cast<hipError_t>(mpc::launch_stream_assembly(sa, behind)));
         EntropyBuffers eb = ent[sl];
         if (device_entropy) {
@@ -1787,7 +1777,7 @@ static mpc_status encode_sequence(mpc_context* c, const uint8_t* const* frames, 
             if (device_entropy) {
                 uint8_t* blob = nullptr;
                 size_t n = 0;
-                const EntropyResult r = finish_entropy_on_device(eb, bs, width, height, K, q, phase2_beside ? down : pursuit_stream, ev_down,
+                const EntropyResult r = finish_entropy_on_device(eb, bs, width, height, K, q, down, ev_down,
                                                                  [&] { tell(); }, &blob, &n, tr.e, single);
                 tr.t2 = tr.t3 = now_ms();
                 if (r == EntropyResult::kDone) return {blob, n};

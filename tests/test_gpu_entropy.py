@@ -69,9 +69,9 @@ def test_host_route_gives_the_same_bytes(ia, oracle):
     octx = oracle.OracleContext(8, 8, 3.5)
     want = [hashlib.sha256(octx.encode_image(synth_frame(328, 200, 12345 + f))).hexdigest() for f in range(9)]
     # forced from the start; taken behind a completed phase 1 (more distinct symbols than the triple list may hold); device
-    # ... and the frame pipeline's other schedules (everything on one stream; only phase 2 beside it)
-    for env in ({"MPC_HOST_ENTROPY": "1"}, {"MPC_ENTROPY_TRIPLES": "50"}, {"MPC_HOST_ENTROPY": "0"}, {"MPC_PHASE2_BESIDE": "0"},
-                {"MPC_ASSEMBLY_BESIDE": "0"}):
+    # ... and the frame pipeline's other schedules (one side stream per slot, no stream priorities, the pursuits on every CU, deeper lags)
+    for env in ({"MPC_HOST_ENTROPY": "1"}, {"MPC_ENTROPY_TRIPLES": "50"}, {"MPC_HOST_ENTROPY": "0"}, {"MPC_SHARED_SIDE_STREAMS": "0"},
+                {"MPC_SIDE_PRIORITY": "0", "MPC_SEQ_WORKGROUPS": "0"}, {"MPC_LAG_ASSEMBLY": "3", "MPC_LAG_PHASE2": "4"}):
         r = subprocess.run([sys.executable, "-c", _CHILD.format(root=ROOT)], capture_output=True, text=True, timeout=600,
                            env={**os.environ, **env})
         assert r.returncode == 0, r.stderr
