@@ -107,6 +107,24 @@ def test_huffman_large_and_many_ties(ia, oracle):
         assert (ia.huffman_decode(blob) == data).all()
 
 
+def test_huffman_heap_order_on_many_small_tie_heavy_alphabets(ia, oracle):
+    """The reference's priority_queue orders by frequency alone: among equal frequencies the heap algorithm itself decides, and the
+    product restates libstdc++'s push_heap / pop_heap step for step on packed words (host_bitstream.cpp: FrequencyHeap).  Every heap
+    size from 1 to 130 leaves (both parities of every level) and a few hundred random larger ones, frequencies from a handful of
+    values so that almost everything ties, against the oracle's own heap."""
+    rng = np.random.default_rng(77)
+    sizes = list(range(1, 131)) + [int(x) for x in rng.integers(131, 2500, 120)]
+    for n in sizes:
+        symbols = rng.choice(65536, size=n, replace=False).astype(np.uint16)
+        counts = rng.choice([1, 1, 1, 2, 2, 3, 5, 8], size=n)
+        data = np.repeat(symbols, counts)
+        rng.shuffle(data)
+        blob = ia.huffman_encode(data)
+        assert blob == _oracle_huffman(oracle, data), n
+    data = np.repeat(rng.choice(65536, size=40000, replace=False).astype(np.uint16), 1)      # 40 000 leaves, all ties
+    assert ia.huffman_encode(data) == _oracle_huffman(oracle, data)
+
+
 def test_huffman_decode_fast_paths(ia, oracle):
     """The decoder's fast loop (bit buffer, one- or two-symbol table, second-level tables for codes longer than the window) and
     its fall-backs: geometric frequencies (code lengths up to the twenties: sub-tables), Fibonacci frequencies (lengths beyond 26:
