@@ -310,6 +310,28 @@ def test_symbol_streams_direct_and_planned_routes_equal_the_oracle(ia, oracle):
     assert planned == want
 
 
+def test_planned_route_with_symbols_that_first_appear_millions_of_positions_in(ia, oracle):
+    """plan_stream orders a stream's symbols by first appearance with a radix sort, 11 bits of the position a pass: first
+    appearances beyond 2^22 take the third pass, alphabets under 128 symbols a comparison sort -- both against the oracle."""
+    import stream_cases
+    rng = np.random.default_rng(5)
+    W = H = 8 * 900
+    K, tiles = 2, 900 * 900
+    late = np.concatenate([rng.integers(0, 3, 4_300_000), rng.permutation(np.arange(3, 700)), rng.integers(0, 700, 5000)]).astype(np.uint16)
+    few = np.concatenate([np.zeros(4_250_000, np.uint16), rng.integers(0, 90, 20000).astype(np.uint16)])   # long runs: run-length coded
+    streams = [late, rng.integers(0, 50, 1000).astype(np.uint16), few] + [np.zeros(0, np.uint16)] * (6 * K - 3)
+    assert sum(len(x) for x in streams) <= 2 * 3 * tiles * K
+    counts = rng.integers(0, K + 1, 3 * tiles).astype(np.uint16)
+    q = stream_cases.quant(K)
+    planned = ia.assemble_symbol_streams(W, H, K, 8, q, counts, streams, by_plan=True)
+    direct = ia.assemble_symbol_streams(W, H, K, 8, q, counts, streams)
+    assert planned == direct
+    # the oracle takes the DC slot (stream 1) before differencing: an empty one needs none
+    streams_o = [late, np.zeros(0, np.uint16), few] + [np.zeros(0, np.uint16)] * (6 * K - 3)
+    want = oracle.write_compressed(dict(W=W, H=H, K=K, bs=8, quant=q, lengths=counts, codes=streams_o))
+    assert ia.assemble_symbol_streams(W, H, K, 8, q, counts, streams_o, by_plan=True) == want
+
+
 def test_container_jobs_refuse_misuse_without_touching_a_device(ia):
     """mpc_container_job_*: a host-only context has no device (begin), a slot that has not begun has no tables to build, one
     without tables nothing to collect, and slots are bounded -- status codes, no HIP call."""
