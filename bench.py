@@ -429,7 +429,9 @@ def main():
                     "kernels of the neighbouring frames on the rest).  achieved = MFMA flops the kernel itself counted (every v_mfma_f32_16x16x32_bf16 executed, 16384 flop each) "
                     "/ that duration, against the dense bf16 peak.  fabric_frac_raw = traffic / duration / 8 TB/s; fabric_frac_2x applies "
                     "the guide's gfx950 correction (2 x FETCH_SIZE, valid for 16 B/lane streams) and is an upper bound.  Neither roof "
-                    "binds: per-step latency does (DESIGN.md 3, 9)"}
+                    "binds: per-step latency does, and with every CU at work the device's power limit (stamps build: shader clock "
+                    "2.37 GHz on 64 workgroups, about 1.8 GHz on 256, profiles/r03_stamps.txt -- against the MFMA peak at that clock "
+                    "frac would be about 0.31; DESIGN.md 3, 9)"}
         line = {
             "metric": "encode Mpixels/s at quality=3.5" if q == 3.5 else f"encode Mpixels/s at quality={q}",
             "value": round(value, 3),
